@@ -1,0 +1,312 @@
+// bzx_api.hip -- C ABI (include/bzx.h), context and batch orchestration of the stage kernels.
+//
+// Host side of the boundary described in include/bzx.h.  Mirrors the reference's driver
+// (src/compression/compress.rs:40-136) but batch-shaped: every stage kernel runs once over
+// all blocks of the batch, one workgroup per block, on one HIP stream; HIP events around
+// each stage feed bzx_stats.  No CPU implementation of any stage exists here.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <string>
+#include <vector>
+#include "../../include/bzx.h"
+#include "bzx_device.h"
+
+void bzx_launch_bwt(const BzxBatch &B, uint32_t grid, hipStream_t stream);
+void bzx_launch_mtf(const BzxBatch &B, uint32_t grid, hipStream_t stream);
+void bzx_launch_huffman(const BzxBatch &B, uint32_t grid, hipStream_t stream);
+void bzx_launch_emit(const BzxBatch &B, uint32_t grid, hipStream_t stream);
+void bzx_launch_layout(const BzxBatch &B, uint64_t first_bit, uint64_t stride_bits, uint64_t *d_total_bits,
+                       hipStream_t stream);
+void bzx_launch_stream_frame(const BzxBatch &B, int level, const uint64_t *d_total_bits, uint64_t *d_out_bytes,
+                             hipStream_t stream);
+int bzx_split_device(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t *nblk_out);
+uint32_t bzx_bwt_max_blocks_per_cu();
+
+struct bzx_ctx {
+    int device = 0;
+    int n_cu = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    uint32_t cap_blocks = 0;   // per-block slab capacity
+    uint32_t n_slots = 0;      // per-workgroup scratch slots
+    BzxBatch B;                // device pointers (by value into kernels)
+    std::vector<void *> slabs; // everything hipMalloc'ed for cap_blocks
+    std::vector<void *> slot_allocs;
+    uint8_t *d_in = nullptr;   // block slab buffer owned by the context
+    uint32_t *d_counters = nullptr;
+    uint64_t *d_scalars = nullptr;   // [0] total bits, [1] out bytes
+    BzxBlock *h_blk = nullptr;       // pinned mirror
+    uint64_t *h_scalars = nullptr;   // pinned
+    hipEvent_t ev[8];
+    bzx_stats stats;
+
+    // device split scratch (bzx_rle1.hip)
+    void *split_ws = nullptr;
+    size_t split_ws_bytes = 0;
+};
+
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                      \
+            return BZX_E_HIP;                                                                    \
+        }                                                                                        \
+    } while (0)
+
+extern "C" const char *bzx_version(void) { return "bzx 0.1 (gfx950)"; }
+
+extern "C" const char *bzx_strerror(int code)
+{
+    switch (code) {
+    case BZX_OK: return "ok";
+    case BZX_E_NODEVICE: return "no HIP device";
+    case BZX_E_PARAM: return "bad parameter";
+    case BZX_E_NOMEM: return "out of memory";
+    case BZX_E_OUTBUF: return "output buffer too small";
+    case BZX_E_HIP: return "HIP runtime error";
+    case BZX_E_STATE: return "bad call sequence";
+    default: return "unknown error";
+    }
+}
+
+extern "C" const char *bzx_last_error(const bzx_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+template <typename T> static int dev_alloc(bzx_ctx *ctx, std::vector<void *> &owner, T **p, size_t count)
+{
+    void *v = nullptr;
+    hipError_t e = hipMalloc(&v, count * sizeof(T));
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return BZX_E_NOMEM;
+    }
+    owner.push_back(v);
+    *p = (T *)v;
+    return BZX_OK;
+}
+
+static void free_all(std::vector<void *> &v)
+{
+    for (void *p : v) (void)hipFree(p);
+    v.clear();
+}
+
+// Per-block slabs for `nblk` blocks.
+static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk)
+{
+    if (nblk <= ctx->cap_blocks) return BZX_OK;
+    free_all(ctx->slabs);
+    ctx->cap_blocks = 0;
+    uint32_t cap = nblk < 16 ? 16 : nblk;
+    BzxBatch &B = ctx->B;
+    int rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &B.blk, cap))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &ctx->d_in, (size_t)cap * BZX_BLK_STRIDE))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &B.bwt, (size_t)cap * BZX_BLK_STRIDE))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &B.rank, (size_t)cap * BZX_BLK_STRIDE))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &B.mtfv, (size_t)cap * BZX_BLK_STRIDE))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &B.freq, (size_t)cap * 260))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &B.in_use, (size_t)cap * 256))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &B.len, (size_t)cap * 6 * 260))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &B.code, (size_t)cap * 6 * 260))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &B.selector, (size_t)cap * BZX_SEL_STRIDE))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &B.selector_mtf, (size_t)cap * BZX_SEL_STRIDE))) return rc;
+    if (ctx->h_blk) (void)hipHostFree(ctx->h_blk);
+    ctx->h_blk = nullptr;
+    if (hipHostMalloc((void **)&ctx->h_blk, (size_t)cap * sizeof(BzxBlock), 0) != hipSuccess) return BZX_E_NOMEM;
+    ctx->cap_blocks = cap;
+    return BZX_OK;
+}
+
+static int ensure_slots(bzx_ctx *ctx, uint32_t n_slots)
+{
+    if (n_slots <= ctx->n_slots) return BZX_OK;
+    free_all(ctx->slot_allocs);
+    ctx->n_slots = 0;
+    std::vector<BzxSortWs> h(n_slots);
+    int rc;
+    // one slab per array kind, carved per slot (a few large allocations instead of thousands)
+    uint64_t *u = nullptr;
+    uint32_t *w = nullptr;
+    if ((rc = dev_alloc(ctx, ctx->slot_allocs, &u, (size_t)n_slots * 2 * BZX_MAX_N))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slot_allocs, &w, (size_t)n_slots * 4 * BZX_MAX_N))) return rc;
+    for (uint32_t i = 0; i < n_slots; i++) {
+        h[i].u0 = u + (size_t)i * 2 * BZX_MAX_N;
+        h[i].u1 = h[i].u0 + BZX_MAX_N;
+        h[i].s0 = w + (size_t)i * 4 * BZX_MAX_N;
+        h[i].s1 = h[i].s0 + BZX_MAX_N;
+        h[i].isa = h[i].s1 + BZX_MAX_N;
+        h[i].sa = h[i].isa + BZX_MAX_N;
+    }
+    if ((rc = dev_alloc(ctx, ctx->slot_allocs, &ctx->B.sort_ws, (size_t)n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slot_allocs, &ctx->B.mtf_ws, (size_t)n_slots * BZX_MTF_WS))) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->B.sort_ws, h.data(), n_slots * sizeof(BzxSortWs), hipMemcpyHostToDevice));
+    ctx->n_slots = n_slots;
+    ctx->B.n_slots = n_slots;
+    return BZX_OK;
+}
+
+extern "C" int bzx_ctx_create(int device, uint32_t max_blocks, bzx_ctx **out)
+{
+    if (!out) return BZX_E_PARAM;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BZX_E_NODEVICE;
+    if (hipSetDevice(device) != hipSuccess) return BZX_E_NODEVICE;
+    bzx_ctx *ctx = new (std::nothrow) bzx_ctx();
+    if (!ctx) return BZX_E_NOMEM;
+    memset(&ctx->B, 0, sizeof(ctx->B));
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        delete ctx;
+        return BZX_E_NODEVICE;
+    }
+    ctx->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) {
+        delete ctx;
+        return BZX_E_NODEVICE;
+    }
+    ctx->own_stream = true;
+    for (int i = 0; i < 8; i++) (void)hipEventCreate(&ctx->ev[i]);
+    bool ok = hipMalloc((void **)&ctx->d_counters, 64 * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&ctx->d_scalars, 8 * sizeof(uint64_t)) == hipSuccess &&
+              hipHostMalloc((void **)&ctx->h_scalars, 8 * sizeof(uint64_t), 0) == hipSuccess;
+    if (!ok || ensure_blocks(ctx, max_blocks ? max_blocks : 16) != BZX_OK) {
+        bzx_ctx_destroy(ctx);
+        return BZX_E_NOMEM;
+    }
+    *out = ctx;
+    return BZX_OK;
+}
+
+extern "C" void bzx_ctx_destroy(bzx_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_all(ctx->slabs);
+    free_all(ctx->slot_allocs);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
+    if (ctx->split_ws) (void)hipFree(ctx->split_ws);
+    if (ctx->h_blk) (void)hipHostFree(ctx->h_blk);
+    if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+    for (int i = 0; i < 8; i++) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int bzx_ctx_set_stream(bzx_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return BZX_E_PARAM;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return BZX_OK;
+}
+
+extern "C" int bzx_get_stats(const bzx_ctx *ctx, bzx_stats *out)
+{
+    if (!ctx || !out) return BZX_E_PARAM;
+    *out = ctx->stats;
+    return BZX_OK;
+}
+
+// Number of workgroups for a one-workgroup-per-block kernel over nblk blocks.
+static uint32_t grid_for(const bzx_ctx *ctx, uint32_t nblk, uint32_t per_cu)
+{
+    uint32_t g = (uint32_t)ctx->n_cu * per_cu;
+    return nblk < g ? nblk : g;
+}
+
+enum { STG_BWT = 1, STG_MTF = 2, STG_HUF = 4, STG_EMIT = 8, STG_ALL = 15 };
+
+// Runs the stage kernels over blocks [0,nblk) whose descriptors (in_off,n,crc) are already on the device.
+static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages)
+{
+    BzxBatch &B = ctx->B;
+    B.nblk = nblk;
+    B.counters = ctx->d_counters;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 64 * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (stages & STG_BWT) {
+        uint32_t per_cu = bzx_bwt_max_blocks_per_cu();
+        uint32_t grid = grid_for(ctx, nblk, per_cu);
+        int rc = ensure_slots(ctx, (uint32_t)ctx->n_cu * per_cu);
+        if (rc) return rc;
+        bzx_launch_bwt(B, grid, ctx->stream);
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (stages & STG_MTF) {
+        int rc = ensure_slots(ctx, (uint32_t)ctx->n_cu);
+        if (rc) return rc;
+        bzx_launch_mtf(B, grid_for(ctx, nblk, 1), ctx->stream);
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (stages & STG_HUF) bzx_launch_huffman(B, grid_for(ctx, nblk, 2), ctx->stream);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    return BZX_OK;
+}
+
+static int check_blk_args(const uint8_t *p, size_t n)
+{
+    if (!p || n == 0 || n > BZX_MAX_BLOCK) return BZX_E_PARAM;
+    return BZX_OK;
+}
+
+extern "C" int bzx_stage_bwt(bzx_ctx *ctx, const uint8_t *blk, size_t n, uint8_t *bwt_out, uint32_t *orig_ptr,
+                             uint32_t *status)
+{
+    if (!ctx || !bwt_out || !orig_ptr || check_blk_args(blk, n)) return BZX_E_PARAM;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_blocks(ctx, 1);
+    if (rc) return rc;
+    memset(&ctx->h_blk[0], 0, sizeof(BzxBlock));
+    ctx->h_blk[0].in_off = 0;
+    ctx->h_blk[0].n = (uint32_t)n;
+    ctx->B.in = ctx->d_in;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_in, blk, n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->B.blk, ctx->h_blk, sizeof(BzxBlock), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = run_stages(ctx, 1, STG_BWT))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(bwt_out, ctx->B.bwt, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_blk, ctx->B.blk, sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *orig_ptr = ctx->h_blk[0].orig_ptr;
+    if (status) *status = ctx->h_blk[0].status;
+    return BZX_OK;
+}
+
+// Debug/bench helper (not part of include/bzx.h): replicate one block `reps` times as a batch, run the
+// given stages, return the HIP-event time of each stage in ms[4] (bwt, mtf, huffman, emit).
+extern "C" int bzx_dbg_time_stages(bzx_ctx *ctx, const uint8_t *blk, size_t n, uint32_t reps, int stages, float ms[4])
+{
+    if (!ctx || check_blk_args(blk, n) || reps == 0) return BZX_E_PARAM;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_blocks(ctx, reps);
+    if (rc) return rc;
+    ctx->B.in = ctx->d_in;
+    for (uint32_t b = 0; b < reps; b++) {
+        memset(&ctx->h_blk[b], 0, sizeof(BzxBlock));
+        ctx->h_blk[b].in_off = (uint64_t)b * BZX_BLK_STRIDE;
+        ctx->h_blk[b].n = (uint32_t)n;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_in + (size_t)b * BZX_BLK_STRIDE, blk, n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->B.blk, ctx->h_blk, reps * sizeof(BzxBlock), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = run_stages(ctx, reps, stages))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 3; i++) {
+        ms[i] = 0.f;
+        (void)hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]);
+    }
+    ms[3] = 0.f;
+    return BZX_OK;
+}

@@ -1,0 +1,71 @@
+// bzx_device.h -- shared device/host definitions for the MI355X bzip2 block pipeline.
+//
+// Execution model: ONE workgroup owns ONE bzip2 block for the whole of a stage kernel and
+// pulls the next block from an atomic work counter when it is done.  Blocks are independent
+// (reference src/compression/compress_block.rs:3-8), so no stage needs inter-workgroup
+// communication; a batch of >= 256 blocks fills the 256 CUs.  All intermediates of a block
+// stay in HBM slabs addressed from the block descriptor below.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#define BZX_MAX_N 900000u          // libbz2 block arrays hold 100000*level bytes
+#define BZX_BLK_STRIDE 900096u     // per-block byte slab stride (multiple of 256)
+#define BZX_MAX_ALPHA 258
+#define BZX_G_SIZE 50
+#define BZX_N_ITERS 4
+#define BZX_MAX_SEL 18002          // ceil(900001 / 50)
+#define BZX_SEL_STRIDE 18048
+
+#define BZX_ST_PERIODIC 1u         // block is u^k, k>1: identical rotations exist
+
+// Per-block descriptor, device resident; filled by the splitter (or the host for the
+// per-block entry points), completed by each stage.
+struct BzxBlock {
+    uint64_t in_off;        // byte offset of the RLE1'd block in the block slab buffer
+    uint32_t n;             // RLE1'd length (1..BZX_MAX_N)
+    uint32_t crc;           // CRC-32/BZIP2 of the raw bytes the block covers
+    uint32_t orig_ptr;      // BWT: row of rotation 0
+    uint32_t status;        // BZX_ST_*
+    uint32_t n_mtf;         // MTF/RLE2: number of symbols incl. EOB
+    uint32_t n_in_use;      // distinct byte values in the block
+    uint32_t n_groups;      // Huffman: coding tables 2..6
+    uint32_t n_selectors;   // ceil(n_mtf / 50)
+    uint64_t bits;          // size of the block image in bits (header .. last payload bit)
+    uint64_t out_bit;       // bit position of the block image in the output buffer
+    uint32_t sec_bits[4];   // [0] selectors, [1] coding tables, [2] payload, [3] symbol map
+    uint32_t pad_[2];
+};
+
+// Per-workgroup-slot scratch of the suffix sorter (one slot per resident workgroup).
+struct BzxSortWs {
+    uint64_t *u0;           // record ping  [BZX_MAX_N]
+    uint64_t *u1;           // record pong  [BZX_MAX_N]
+    uint32_t *s0;           // slot map ping [BZX_MAX_N]
+    uint32_t *s1;           // slot map pong [BZX_MAX_N]
+    uint32_t *isa;          // rank of every rotation [BZX_MAX_N]
+    uint32_t *sa;           // rotation index at every sorted position [BZX_MAX_N]
+};
+
+// Everything a stage kernel needs for a batch of blocks.
+struct BzxBatch {
+    BzxBlock *blk;          // [nblk]
+    uint32_t nblk;
+    uint32_t *counters;     // [8] atomic work counters, one per stage kernel (zeroed per batch)
+    const uint8_t *in;      // block slab buffer (RLE1'd bytes), block b at blk[b].in_off
+    uint8_t *bwt;           // [nblk][BZX_BLK_STRIDE]  last column L
+    uint8_t *rank;          // [nblk][BZX_BLK_STRIDE]  MTF rank of every L byte
+    uint16_t *mtfv;         // [nblk][BZX_BLK_STRIDE]  symbols (RUNA/RUNB/rank+1/EOB)
+    uint32_t *freq;         // [nblk][260]             symbol histogram
+    uint8_t *in_use;        // [nblk][256]
+    uint8_t *len;           // [nblk][6][260]          code lengths
+    uint32_t *code;         // [nblk][6][260]          canonical codes
+    uint8_t *selector;      // [nblk][BZX_SEL_STRIDE]
+    uint8_t *selector_mtf;  // [nblk][BZX_SEL_STRIDE]
+    uint32_t *out;          // output bit buffer (zeroed), big-endian bit order
+    BzxSortWs *sort_ws;     // [n_slots]
+    uint8_t *mtf_ws;        // [n_slots][BZX_MTF_WS]   recency lists of the MTF kernel
+    uint32_t n_slots;
+};
+
+#define BZX_MTF_WS (72u * 1024u)

@@ -1,0 +1,134 @@
+/*
+ * bzx.h -- C ABI of the MI355X-native bzip2 block-compression core (libbzx.so).
+ *
+ * This is the drop-in boundary for the per-block hot path of ohsnyt/bzip2-rust
+ * (RLE1 -> BWT -> MTF -> RLE2 -> multi-table Huffman -> bit packing).  The reference has
+ * no FFI of its own; the seam is the Rust function
+ *     pub fn compress_block(block: &[u8], block_crc: u32) -> (Vec<u8>, u8)
+ *                                               src/compression/compress_block.rs:24
+ * its producer RLE1Block (src/tools/rle1.rs:33-263) and its consumer BitWriter
+ * (src/bitstream/bitwriter.rs:42-172).  Every entry point below names the reference
+ * interface it replaces.  INTEGRATION.md shows the Rust `extern "C"` block a maintainer
+ * would add.  Plain pointers and sizes only; all functions return 0 or a negative
+ * BZX_E_* code and never unwind.
+ *
+ * Output bits are those of C bzip2 1.0.8 (libbz2), which BASELINE.json's metric names;
+ * where the Rust reference diverges from libbz2 libbz2 wins.
+ *
+ * There is NO CPU implementation behind this ABI: every compute entry point needs a HIP
+ * device and fails with BZX_E_NODEVICE without one.
+ */
+#ifndef BZX_H
+#define BZX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BZX_OK 0
+#define BZX_E_NODEVICE (-1)   /* no HIP device / HIP runtime error at init */
+#define BZX_E_PARAM (-2)      /* bad argument (null pointer, n == 0, n > 900000, level not 1..9) */
+#define BZX_E_NOMEM (-3)      /* host or device allocation failed */
+#define BZX_E_OUTBUF (-4)     /* output buffer too small */
+#define BZX_E_HIP (-5)        /* HIP runtime error during a call (see bzx_last_error) */
+#define BZX_E_STATE (-6)      /* call sequence error (stream API) */
+
+#define BZX_MAX_BLOCK 900000u
+
+typedef struct bzx_ctx bzx_ctx;
+
+/* Library / device management (replaces the rayon global pool, compress.rs:128). */
+const char *bzx_version(void);
+const char *bzx_strerror(int code);
+/* HIP error text of the last failing call on this context ("" if none). */
+const char *bzx_last_error(const bzx_ctx *ctx);
+/* device: HIP device ordinal.  max_blocks: expected batch size (slabs grow on demand). */
+int bzx_ctx_create(int device, uint32_t max_blocks, bzx_ctx **out);
+void bzx_ctx_destroy(bzx_ctx *ctx);
+/* Run all work of this context on an existing HIP stream (hipStream_t passed as void*). */
+int bzx_ctx_set_stream(bzx_ctx *ctx, void *hip_stream);
+
+/*
+ * compress_block (compress_block.rs:24-67).  blk = one RLE1'd block, crc = CRC of the raw
+ * bytes it covers.  out receives the byte-aligned block image (48-bit magic, crc, randomised
+ * bit, origPtr, symbol map, selectors, coding tables, payload), last byte zero padded;
+ * *pad_bits = number of pad bits (0..7), i.e. BitPacker::padding (bitpacker.rs:20-21).
+ * Host pointers.  cap >= n + n/50 + 1024 is always enough.
+ */
+int bzx_compress_block(bzx_ctx *ctx, const uint8_t *blk, size_t n, uint32_t crc, uint8_t *out, size_t cap,
+                       size_t *out_len, uint8_t *pad_bits);
+
+/*
+ * Batched form: what the rayon fan-out over blocks (compress.rs:125-132) becomes.  All
+ * nblk blocks are resident on the device at once and every stage kernel runs over the
+ * whole batch.  Host pointers.
+ */
+int bzx_compress_blocks(bzx_ctx *ctx, uint32_t nblk, const uint8_t *const *blks, const size_t *ns,
+                        const uint32_t *crcs, uint8_t *const *outs, const size_t *caps, size_t *out_lens,
+                        uint8_t *pads);
+
+/*
+ * Stage entry points (host pointers), one per stage function of the reference, used by the
+ * parity tests to compare each device stage with the oracle:
+ *   bzx_stage_bwt       bwt_encode            src/bwt_algorithms/bwt_sort.rs:27
+ *   bzx_stage_mtf       rle2_mtf_encode       src/tools/rle2_mtf.rs:23
+ *   bzx_stage_huffman   huf_encode tables     src/huffman_coding/huffman.rs:87-374
+ */
+int bzx_stage_bwt(bzx_ctx *ctx, const uint8_t *blk, size_t n, uint8_t *bwt_out, uint32_t *orig_ptr,
+                  uint32_t *status);
+int bzx_stage_mtf(bzx_ctx *ctx, const uint8_t *bwt, size_t n, uint16_t *mtfv_out, uint32_t *n_mtf,
+                  uint32_t freq_out[258], uint8_t in_use_out[256]);
+int bzx_stage_huffman(bzx_ctx *ctx, const uint16_t *mtfv, uint32_t n_mtf, const uint32_t freq[258],
+                      uint32_t alpha_size, uint32_t *n_groups, uint32_t *n_selectors, uint8_t *selectors,
+                      uint8_t len_out[6][258], uint32_t code_out[6][258]);
+
+/*
+ * RLE1 + block split + per-block CRC (replaces RLE1Block, rle1.rs:33-263, and do_crc,
+ * crc.rs:15-22) with libbz2's split rule.  Host pointers; whole input at once.
+ * blocks_out: nblk_cap slabs of BZX_MAX_BLOCK bytes; ns/crcs: per block.  *nblk = blocks made.
+ */
+int bzx_split_rle1(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level, uint8_t *blocks_out,
+                   uint32_t nblk_cap, uint32_t *ns, uint32_t *crcs, uint32_t *nblk);
+
+/*
+ * Whole buffer -> .bz2 with every stage on the device (replaces compress(), compress.rs:40-136,
+ * minus file I/O).  d_raw / d_out are DEVICE pointers (HBM); nothing but the final length
+ * crosses PCIe.  cap >= len + len/50 + 4096.
+ */
+int bzx_compress_device(bzx_ctx *ctx, const void *d_raw, size_t len, int level, void *d_out, size_t cap,
+                        size_t *out_len);
+/* Same with host buffers (H2D, device pipeline, D2H). */
+int bzx_compress_buffer(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level, uint8_t *out, size_t cap,
+                        size_t *out_len);
+
+/* Per-call telemetry of the last bzx_compress_device/_buffer/_blocks call. */
+typedef struct {
+    uint32_t nblk;
+    uint32_t n_periodic;        /* blocks flagged periodic */
+    uint64_t raw_bytes;         /* N_b summed */
+    uint64_t rle1_bytes;        /* n summed */
+    uint64_t mtf_symbols;       /* nMTF summed */
+    uint64_t out_bits;          /* compressed bits incl. stream header/footer when present */
+    float ms_split, ms_bwt, ms_mtf, ms_huffman, ms_emit, ms_total;   /* HIP-event times of the stage kernels */
+} bzx_stats;
+int bzx_get_stats(const bzx_ctx *ctx, bzx_stats *out);
+
+/*
+ * Stream assembler (replaces BitWriter, bitwriter.rs:42-172): header "BZh<level>", bit-granular
+ * append of block images minus their padding, footer magic + combined CRC (crc.rs:25-27).
+ * Host-side; used with bzx_compress_block(s) when the caller keeps the reference's structure.
+ */
+typedef struct bzx_stream bzx_stream;
+int bzx_stream_begin(int level, bzx_stream **out);
+int bzx_stream_append_block(bzx_stream *s, const uint8_t *data, size_t len, uint8_t pad_bits);
+/* Finishes the stream; *data stays valid until bzx_stream_free. */
+int bzx_stream_finish(bzx_stream *s, const uint8_t **data, size_t *len);
+void bzx_stream_free(bzx_stream *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

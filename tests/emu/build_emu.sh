@@ -1,0 +1,10 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE: builds the kernels for the CPU fiber emulator (logic debugging only).
+set -e
+cd "$(dirname "$0")/../.."
+SRCS=$(ls bzip2-rust_amd/csrc/*.hip)
+ARGS=""
+for s in $SRCS; do ARGS="$ARGS -x c++ $s"; done
+g++ -O1 -g -std=c++17 -fPIC -shared -w -I tests/emu $ARGS -x c++ tests/emu/hip_emu.cpp \
+    -Wl,--unresolved-symbols=ignore-all -o tests/emu/libbzx_emu.so
+echo built tests/emu/libbzx_emu.so
