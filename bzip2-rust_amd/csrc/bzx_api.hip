@@ -38,6 +38,7 @@ struct bzx_ctx {
     std::vector<void *> slabs; // everything hipMalloc'ed for cap_blocks
     std::vector<void *> slot_allocs;
     uint8_t *d_in = nullptr;   // block slab buffer owned by the context
+    uint32_t *d_outbuf = nullptr;   // per-block output slabs (per-block entry points)
     uint32_t *d_counters = nullptr;
     uint64_t *d_scalars = nullptr;   // [0] total bits, [1] out bytes
     BzxBlock *h_blk = nullptr;       // pinned mirror
@@ -116,6 +117,8 @@ static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk)
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.code, (size_t)cap * 6 * 260))) return rc;
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.selector, (size_t)cap * BZX_SEL_STRIDE))) return rc;
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.selector_mtf, (size_t)cap * BZX_SEL_STRIDE))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &B.gbits, (size_t)cap * BZX_SEL_STRIDE))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &ctx->d_outbuf, (size_t)cap * (BZX_OUT_STRIDE / 4)))) return rc;
     if (ctx->h_blk) (void)hipHostFree(ctx->h_blk);
     ctx->h_blk = nullptr;
     if (hipHostMalloc((void **)&ctx->h_blk, (size_t)cap * sizeof(BzxBlock), 0) != hipSuccess) return BZX_E_NOMEM;
@@ -230,14 +233,17 @@ static uint32_t grid_for(const bzx_ctx *ctx, uint32_t nblk, uint32_t per_cu)
 enum { STG_BWT = 1, STG_MTF = 2, STG_HUF = 4, STG_EMIT = 8, STG_ALL = 15 };
 
 // Runs the stage kernels over blocks [0,nblk) whose descriptors (in_off,n,crc) are already on the device.
-static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages)
+// STG_EMIT: out_level == 0 -> every block image byte-aligned in its own slab of ctx->d_outbuf;
+//           out_level 1..9 -> one .bz2 stream in d_stream_out (cap bytes, device memory).
+static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0, void *d_stream_out = nullptr,
+                      size_t stream_cap = 0)
 {
     BzxBatch &B = ctx->B;
     B.nblk = nblk;
     B.counters = ctx->d_counters;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 64 * sizeof(uint32_t), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    if (stages & STG_BWT) {
+    if ((stages & STG_BWT) && nblk) {
         uint32_t per_cu = bzx_bwt_max_blocks_per_cu();
         uint32_t grid = grid_for(ctx, nblk, per_cu);
         int rc = ensure_slots(ctx, (uint32_t)ctx->n_cu * per_cu);
@@ -245,16 +251,37 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages)
         bzx_launch_bwt(B, grid, ctx->stream);
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    if (stages & STG_MTF) {
-        int rc = ensure_slots(ctx, (uint32_t)ctx->n_cu);
-        if (rc) return rc;
-        bzx_launch_mtf(B, grid_for(ctx, nblk, 1), ctx->stream);
-    }
+    if ((stages & STG_MTF) && nblk) bzx_launch_mtf(B, grid_for(ctx, nblk, 1), ctx->stream);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    if (stages & STG_HUF) bzx_launch_huffman(B, grid_for(ctx, nblk, 2), ctx->stream);
+    if ((stages & STG_HUF) && nblk) bzx_launch_huffman(B, grid_for(ctx, nblk, 2), ctx->stream);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (stages & STG_EMIT) {
+        if (out_level == 0) {
+            B.out = ctx->d_outbuf;
+            bzx_launch_layout(B, 0, (uint64_t)BZX_OUT_STRIDE * 8, ctx->d_scalars, ctx->stream);
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_outbuf, 0, (size_t)nblk * BZX_OUT_STRIDE, ctx->stream));
+            if (nblk) bzx_launch_emit(B, grid_for(ctx, nblk, 2), ctx->stream);
+        } else {
+            B.out = (uint32_t *)d_stream_out;
+            bzx_launch_layout(B, 32, 0, ctx->d_scalars, ctx->stream);
+            HIP_TRY(ctx, hipMemsetAsync(d_stream_out, 0, stream_cap, ctx->stream));
+            if (nblk) bzx_launch_emit(B, grid_for(ctx, nblk, 2), ctx->stream);
+            bzx_launch_stream_frame(B, out_level, ctx->d_scalars, ctx->d_scalars + 1, ctx->stream);
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
     return BZX_OK;
+}
+
+static void collect_stage_times(bzx_ctx *ctx)
+{
+    float ms[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]);
+    ctx->stats.ms_bwt = ms[0];
+    ctx->stats.ms_mtf = ms[1];
+    ctx->stats.ms_huffman = ms[2];
+    ctx->stats.ms_emit = ms[3];
 }
 
 static int check_blk_args(const uint8_t *p, size_t n)
@@ -303,10 +330,145 @@ extern "C" int bzx_dbg_time_stages(bzx_ctx *ctx, const uint8_t *blk, size_t n, u
     HIP_TRY(ctx, hipMemcpyAsync(ctx->B.blk, ctx->h_blk, reps * sizeof(BzxBlock), hipMemcpyHostToDevice, ctx->stream));
     if ((rc = run_stages(ctx, reps, stages))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 4; i++) {
         ms[i] = 0.f;
         (void)hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]);
     }
-    ms[3] = 0.f;
     return BZX_OK;
+}
+
+extern "C" int bzx_stage_mtf(bzx_ctx *ctx, const uint8_t *bwt, size_t n, uint16_t *mtfv_out, uint32_t *n_mtf,
+                             uint32_t freq_out[258], uint8_t in_use_out[256])
+{
+    if (!ctx || !mtfv_out || !n_mtf || !freq_out || !in_use_out || check_blk_args(bwt, n)) return BZX_E_PARAM;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_blocks(ctx, 1);
+    if (rc) return rc;
+    memset(&ctx->h_blk[0], 0, sizeof(BzxBlock));
+    ctx->h_blk[0].n = (uint32_t)n;
+    ctx->B.in = ctx->d_in;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->B.bwt, bwt, n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->B.blk, ctx->h_blk, sizeof(BzxBlock), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = run_stages(ctx, 1, STG_MTF))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_blk, ctx->B.blk, sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t m = ctx->h_blk[0].n_mtf;
+    if (m == 0 || m > n + 1) {
+        ctx->err = "device MTF produced an impossible symbol count";
+        return BZX_E_HIP;
+    }
+    *n_mtf = m;
+    HIP_TRY(ctx, hipMemcpy(mtfv_out, ctx->B.mtfv, (size_t)m * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(freq_out, ctx->B.freq, 258 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(in_use_out, ctx->B.in_use, 256, hipMemcpyDeviceToHost));
+    return BZX_OK;
+}
+
+extern "C" int bzx_stage_huffman(bzx_ctx *ctx, const uint16_t *mtfv, uint32_t n_mtf, const uint32_t freq[258],
+                                 uint32_t alpha_size, uint32_t *n_groups, uint32_t *n_selectors, uint8_t *selectors,
+                                 uint8_t len_out[6][258], uint32_t code_out[6][258])
+{
+    if (!ctx || !mtfv || !freq || !n_groups || !n_selectors || !selectors || !len_out || !code_out) return BZX_E_PARAM;
+    if (n_mtf == 0 || n_mtf > BZX_MAX_BLOCK + 1 || alpha_size < 3 || alpha_size > BZX_MAX_ALPHA) return BZX_E_PARAM;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_blocks(ctx, 1);
+    if (rc) return rc;
+    memset(&ctx->h_blk[0], 0, sizeof(BzxBlock));
+    ctx->h_blk[0].n = n_mtf - 1;
+    ctx->h_blk[0].n_mtf = n_mtf;
+    ctx->h_blk[0].n_in_use = alpha_size - 2;
+    uint32_t f260[260];
+    memset(f260, 0, sizeof(f260));
+    memcpy(f260, freq, 258 * sizeof(uint32_t));
+    HIP_TRY(ctx, hipMemcpy(ctx->B.mtfv, mtfv, (size_t)n_mtf * 2, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->B.freq, f260, sizeof(f260), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(ctx->B.in_use, 0, 256));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->B.blk, ctx->h_blk, sizeof(BzxBlock), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = run_stages(ctx, 1, STG_HUF))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_blk, ctx->B.blk, sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *n_groups = ctx->h_blk[0].n_groups;
+    *n_selectors = ctx->h_blk[0].n_selectors;
+    if (*n_selectors > BZX_MAX_SEL) {
+        ctx->err = "device Huffman stage produced an impossible selector count";
+        return BZX_E_HIP;
+    }
+    HIP_TRY(ctx, hipMemcpy(selectors, ctx->B.selector, *n_selectors, hipMemcpyDeviceToHost));
+    static thread_local uint8_t hl[6 * 260];
+    static thread_local uint32_t hc[6 * 260];
+    HIP_TRY(ctx, hipMemcpy(hl, ctx->B.len, sizeof(hl), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hc, ctx->B.code, sizeof(hc), hipMemcpyDeviceToHost));
+    for (int t = 0; t < 6; t++)
+        for (int v = 0; v < 258; v++) {
+            len_out[t][v] = hl[t * 260 + v];
+            code_out[t][v] = hc[t * 260 + v];
+        }
+    return BZX_OK;
+}
+
+extern "C" int bzx_compress_blocks(bzx_ctx *ctx, uint32_t nblk, const uint8_t *const *blks, const size_t *ns,
+                                   const uint32_t *crcs, uint8_t *const *outs, const size_t *caps, size_t *out_lens,
+                                   uint8_t *pads)
+{
+    if (!ctx || !blks || !ns || !crcs || !outs || !caps || !out_lens || !pads) return BZX_E_PARAM;
+    if (nblk == 0) return BZX_OK;
+    for (uint32_t b = 0; b < nblk; b++)
+        if (check_blk_args(blks[b], ns[b]) || !outs[b]) return BZX_E_PARAM;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_blocks(ctx, nblk);
+    if (rc) return rc;
+    ctx->B.in = ctx->d_in;
+    uint64_t rle1 = 0;
+    for (uint32_t b = 0; b < nblk; b++) {
+        memset(&ctx->h_blk[b], 0, sizeof(BzxBlock));
+        ctx->h_blk[b].in_off = (uint64_t)b * BZX_BLK_STRIDE;
+        ctx->h_blk[b].n = (uint32_t)ns[b];
+        ctx->h_blk[b].crc = crcs[b];
+        rle1 += ns[b];
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_in + (size_t)b * BZX_BLK_STRIDE, blks[b], ns[b], hipMemcpyHostToDevice,
+                                    ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->B.blk, ctx->h_blk, nblk * sizeof(BzxBlock), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = run_stages(ctx, nblk, STG_ALL, 0))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_blk, ctx->B.blk, nblk * sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    collect_stage_times(ctx);
+    bzx_stats &st = ctx->stats;
+    st.nblk = nblk;
+    st.n_periodic = 0;
+    st.raw_bytes = 0;
+    st.rle1_bytes = rle1;
+    st.mtf_symbols = 0;
+    st.out_bits = 0;
+    st.ms_split = 0;
+    int ret = BZX_OK;
+    for (uint32_t b = 0; b < nblk; b++) {
+        const BzxBlock &d = ctx->h_blk[b];
+        const size_t bytes = (size_t)((d.bits + 7) >> 3);
+        st.n_periodic += (d.status & BZX_ST_PERIODIC) ? 1 : 0;
+        st.mtf_symbols += d.n_mtf;
+        st.out_bits += d.bits;
+        if (bytes > BZX_OUT_STRIDE) {
+            ctx->err = "block image larger than its device slab";
+            return BZX_E_HIP;
+        }
+        if (bytes > caps[b]) {
+            ret = BZX_E_OUTBUF;
+            out_lens[b] = bytes;
+            continue;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(outs[b], (const uint8_t *)ctx->d_outbuf + (size_t)b * BZX_OUT_STRIDE, bytes,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        out_lens[b] = bytes;
+        pads[b] = (uint8_t)((8 - (d.bits & 7)) & 7);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    st.ms_total = st.ms_bwt + st.ms_mtf + st.ms_huffman + st.ms_emit;
+    return ret;
+}
+
+extern "C" int bzx_compress_block(bzx_ctx *ctx, const uint8_t *blk, size_t n, uint32_t crc, uint8_t *out, size_t cap,
+                                  size_t *out_len, uint8_t *pad_bits)
+{
+    return bzx_compress_blocks(ctx, 1, &blk, &n, &crc, &out, &cap, out_len, pad_bits);
 }

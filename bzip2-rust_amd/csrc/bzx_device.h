@@ -62,6 +62,7 @@ struct BzxBatch {
     uint32_t *code;         // [nblk][6][260]          canonical codes
     uint8_t *selector;      // [nblk][BZX_SEL_STRIDE]
     uint8_t *selector_mtf;  // [nblk][BZX_SEL_STRIDE]
+    uint16_t *gbits;        // [nblk][BZX_SEL_STRIDE]  payload bits of every 50-symbol group
     uint32_t *out;          // output bit buffer (zeroed), big-endian bit order
     BzxSortWs *sort_ws;     // [n_slots]
     uint8_t *mtf_ws;        // [n_slots][BZX_MTF_WS]   recency lists of the MTF kernel
@@ -69,3 +70,4 @@ struct BzxBatch {
 };
 
 #define BZX_MTF_WS (72u * 1024u)
+#define BZX_OUT_STRIDE 921600u      // per-block output slab for the per-block entry points (bytes)

@@ -1,0 +1,297 @@
+// bzx_emit.hip -- bit emission of a block image, stream layout and stream framing on gfx950.
+//
+// Contract: the bits huf_encode writes after table optimisation (reference
+// src/huffman_coding/huffman.rs:209-466) behind the block header compress_block writes
+// (src/compression/compress_block.rs:34-48), MSB first like BitPacker
+// (src/bitstream/bitpacker.rs:43-84); then what BitWriter does on the host in the reference
+// (src/bitstream/bitwriter.rs:67-132): blocks appended bit-granularly, "BZh<level>" in front,
+// footer magic + combined CRC (src/tools/crc.rs:25-27) behind.
+//
+// Every variable-length item gets its bit offset from an exclusive scan of item sizes, so all
+// items are written independently: one lane per 50-symbol group for the payload, one lane per
+// selector chunk, one lane per coding table.  A lane packs its bits in a 64-bit register and
+// stores whole 32-bit words; only the first and last word of a lane's range can be shared with
+// a neighbour and are merged with atomicOr into the zeroed output buffer.  Because a block's
+// out_bit is its final position in the stream (scan over block sizes, bzx_layout_kernel), no
+// host-side or second-pass bit shifting is needed: the .bz2 is complete in HBM.
+#include <hip/hip_runtime.h>
+#include "bzx_device.h"
+#include "bzx_wg.h"
+
+#define EMIT_NT 512
+#define EMIT_NW (EMIT_NT / 64)
+
+struct BitW {
+    uint32_t *out;
+    uint64_t wi;      // next 32-bit word index
+    uint64_t acc;
+    uint32_t nacc;    // bits held in acc (< 32 between calls)
+    bool first;
+    __device__ __forceinline__ void init(uint32_t *o, uint64_t bitpos)
+    {
+        out = o;
+        wi = bitpos >> 5;
+        nacc = (uint32_t)(bitpos & 31u);   // leading bits belong to the predecessor: zeros here, OR-merged
+        acc = 0;
+        first = true;
+    }
+    __device__ __forceinline__ void flush_word(uint32_t w)
+    {
+        const uint32_t be = __builtin_bswap32(w);
+        if (first) {
+            if (be) atomicOr(&out[wi], be);
+            first = false;
+        } else {
+            out[wi] = be;
+        }
+        wi++;
+    }
+    __device__ __forceinline__ void put(uint32_t nbits, uint32_t val)
+    {
+        if (nbits == 0) return;
+        acc = (acc << nbits) | (uint64_t)val;
+        nacc += nbits;
+        if (nacc >= 32) {
+            nacc -= 32;
+            flush_word((uint32_t)(acc >> nacc));
+            acc &= (1ull << nacc) - 1ull;
+        }
+    }
+    __device__ __forceinline__ void finish()
+    {
+        if (nacc > 0) {
+            const uint32_t be = __builtin_bswap32((uint32_t)(acc << (32 - nacc)));
+            if (be) atomicOr(&out[wi], be);
+        }
+    }
+};
+
+__shared__ uint8_t e_len[6][BZX_MAX_ALPHA + 2];
+__shared__ uint32_t e_code[6][BZX_MAX_ALPHA + 2];
+__shared__ uint32_t e_tabbits[8];
+__shared__ uint32_t e_scratch[2 * EMIT_NW];
+__shared__ uint32_t e_bcast[4];
+
+__global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
+{
+    const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
+
+    for (;;) {
+        if (tid == 0) e_bcast[0] = atomicAdd(&B.counters[3], 1u);
+        __syncthreads();
+        const uint32_t b = e_bcast[0];
+        __syncthreads();
+        if (b >= B.nblk) break;
+
+        const BzxBlock d = B.blk[b];
+        const uint32_t alpha = d.n_in_use + 2, n_mtf = d.n_mtf, n_sel = d.n_selectors, n_groups = d.n_groups;
+        const uint16_t *__restrict__ V = B.mtfv + (size_t)b * BZX_BLK_STRIDE;
+        const uint8_t *__restrict__ SEL = B.selector + (size_t)b * BZX_SEL_STRIDE;
+        const uint8_t *__restrict__ SELM = B.selector_mtf + (size_t)b * BZX_SEL_STRIDE;
+        const uint16_t *__restrict__ GB = B.gbits + (size_t)b * BZX_SEL_STRIDE;
+        uint32_t *out = B.out;
+
+        const uint64_t o_map = d.out_bit + 105;
+        const uint64_t o_ng = o_map + d.sec_bits[3];
+        const uint64_t o_sel = o_ng + 18;
+        const uint64_t o_tab = o_sel + d.sec_bits[0];
+        const uint64_t o_pay = o_tab + d.sec_bits[1];
+
+        for (uint32_t i = tid; i < 6 * 260; i += EMIT_NT) {
+            const uint32_t t = i / 260, v = i % 260;
+            if (v < BZX_MAX_ALPHA + 2) {
+                e_len[t][v] = B.len[(size_t)b * 6 * 260 + i];
+                e_code[t][v] = B.code[(size_t)b * 6 * 260 + i];
+            }
+        }
+        __syncthreads();
+
+        // ---- (a) block header, symbol map, nGroups, nSelectors (compress_block.rs:34-48, huffman.rs:209-224)
+        if (tid == 0) {
+            BitW w;
+            w.init(out, d.out_bit);
+            w.put(24, 0x314159u);
+            w.put(24, 0x265359u);
+            w.put(32, d.crc);
+            w.put(1, 0);
+            w.put(24, d.orig_ptr);
+            uint32_t l1 = 0, words[16];
+            for (uint32_t i = 0; i < 16; i++) {
+                uint32_t wv = 0;
+                for (uint32_t j = 0; j < 16; j++)
+                    if (B.in_use[(size_t)b * 256 + i * 16 + j]) wv |= 0x8000u >> j;
+                words[i] = wv;
+                if (wv) l1 |= 0x8000u >> i;
+            }
+            w.put(16, l1);
+            for (uint32_t i = 0; i < 16; i++)
+                if (words[i]) w.put(16, words[i]);
+            w.put(3, n_groups);
+            w.put(15, n_sel);
+            w.finish();
+        }
+
+        // ---- (b) selectors, unary (huffman.rs:237-292)
+        {
+            const uint32_t per = (n_sel + EMIT_NT - 1) / EMIT_NT;
+            const uint32_t lo = tid * per < n_sel ? tid * per : n_sel;
+            const uint32_t hi = lo + per < n_sel ? lo + per : n_sel;
+            uint32_t my_bits = 0;
+            for (uint32_t i = lo; i < hi; i++) my_bits += SELM[i] + 1u;
+            uint32_t tot;
+            const uint32_t ex = bzx_block_excl_sum<EMIT_NT>(my_bits, e_scratch, tot);
+            if (hi > lo) {
+                BitW w;
+                w.init(out, o_sel + ex);
+                for (uint32_t i = lo; i < hi; i++) {
+                    const uint32_t j = SELM[i];
+                    w.put(j + 1, ((1u << j) - 1u) << 1);
+                }
+                w.finish();
+            }
+        }
+
+        // ---- (c) coding tables, delta coded (huffman.rs:391-438), one lane per table
+        if (lane == 0 && wave < n_groups) {
+            uint32_t bits = 5;
+            int32_t curr = e_len[wave][0];
+            for (uint32_t i = 0; i < alpha; i++) {
+                const int32_t l = e_len[wave][i];
+                bits += 2u * (uint32_t)(l > curr ? l - curr : curr - l) + 1u;
+                curr = l;
+            }
+            e_tabbits[wave] = bits;
+        }
+        __syncthreads();
+        if (lane == 0 && wave < n_groups) {
+            uint64_t pos = o_tab;
+            for (uint32_t t = 0; t < wave; t++) pos += e_tabbits[t];
+            BitW w;
+            w.init(out, pos);
+            int32_t curr = e_len[wave][0];
+            w.put(5, (uint32_t)curr);
+            for (uint32_t i = 0; i < alpha; i++) {
+                const int32_t l = e_len[wave][i];
+                while (curr < l) {
+                    w.put(2, 2);
+                    curr++;
+                }
+                while (curr > l) {
+                    w.put(2, 3);
+                    curr--;
+                }
+                w.put(1, 0);
+            }
+            w.finish();
+        }
+
+        // ---- (d) payload (huffman.rs:452-466): one lane per group, offsets from a scan of group sizes
+        {
+            if (tid == 0) e_bcast[1] = 0;
+            __syncthreads();
+            for (uint32_t g0 = 0; g0 < n_sel; g0 += EMIT_NT) {
+                const uint32_t g = g0 + tid;
+                const uint32_t carry = e_bcast[1];
+                const uint32_t gb = g < n_sel ? (uint32_t)GB[g] : 0u;
+                uint32_t tot;
+                const uint32_t ex = bzx_block_excl_sum<EMIT_NT>(gb, e_scratch, tot);
+                if (g < n_sel) {
+                    const uint32_t gs = g * BZX_G_SIZE;
+                    const uint32_t cnt = (n_mtf - gs < BZX_G_SIZE) ? n_mtf - gs : BZX_G_SIZE;
+                    const uint32_t *__restrict__ vp = reinterpret_cast<const uint32_t *>(V + gs);
+                    const uint32_t bt = SEL[g];
+                    BitW w;
+                    w.init(out, o_pay + carry + ex);
+                    for (uint32_t k = 0; k < BZX_G_SIZE / 2; k++) {
+                        const uint32_t sy = vp[k];
+                        if (2 * k < cnt) {
+                            const uint32_t s = sy & 0xffffu;
+                            w.put(e_len[bt][s], e_code[bt][s]);
+                        }
+                        if (2 * k + 1 < cnt) {
+                            const uint32_t s = sy >> 16;
+                            w.put(e_len[bt][s], e_code[bt][s]);
+                        }
+                    }
+                    w.finish();
+                }
+                if (tid == 0) e_bcast[1] = carry + tot;
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// out_bit of every block: first_bit + exclusive scan of block sizes (stream mode, stride_bits == 0)
+// or b * stride_bits (per-block mode).  total[0] = first_bit + sum of sizes.
+__global__ __launch_bounds__(EMIT_NT) void bzx_layout_kernel(BzxBatch B, uint64_t first_bit, uint64_t stride_bits,
+                                                            uint64_t *total)
+{
+    __shared__ uint64_t l_wsum[EMIT_NW];
+    __shared__ uint64_t l_carry;
+    const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
+    if (tid == 0) l_carry = first_bit;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < B.nblk; b0 += EMIT_NT) {
+        const uint32_t b = b0 + tid;
+        const uint64_t v = b < B.nblk ? B.blk[b].bits : 0ull;
+        uint64_t x = v;
+        for (uint32_t dd = 1; dd < 64; dd <<= 1) {
+            const uint64_t y = __shfl_up(x, dd);
+            if (lane >= dd) x += y;
+        }
+        if (lane == 63) l_wsum[wave] = x;
+        const uint64_t carry = l_carry;
+        __syncthreads();
+        uint64_t pre = 0, tot = 0;
+        for (uint32_t i = 0; i < EMIT_NW; i++) {
+            if (i < wave) pre += l_wsum[i];
+            tot += l_wsum[i];
+        }
+        if (b < B.nblk) B.blk[b].out_bit = stride_bits ? (uint64_t)b * stride_bits : carry + pre + x - v;
+        __syncthreads();
+        if (tid == 0) l_carry = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) total[0] = l_carry;
+}
+
+// "BZh<level>" at bit 0, footer magic + combined CRC behind the last block; out_bytes[0] = stream length.
+__global__ void bzx_stream_frame_kernel(BzxBatch B, int level, const uint64_t *total, uint64_t *out_bytes)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    BitW w;
+    w.init(B.out, 0);
+    w.put(8, 'B');
+    w.put(8, 'Z');
+    w.put(8, 'h');
+    w.put(8, (uint32_t)('0' + level));
+    w.finish();
+    uint32_t combined = 0;
+    for (uint32_t b = 0; b < B.nblk; b++) combined = ((combined << 1) | (combined >> 31)) ^ B.blk[b].crc;
+    const uint64_t end = total[0];
+    w.init(B.out, end);
+    w.put(24, 0x177245u);
+    w.put(24, 0x385090u);
+    w.put(32, combined);
+    w.finish();
+    out_bytes[0] = (end + 80 + 7) >> 3;
+}
+
+void bzx_launch_emit(const BzxBatch &B, uint32_t grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_emit_kernel, dim3(grid), dim3(EMIT_NT), 0, stream, B);
+}
+
+void bzx_launch_layout(const BzxBatch &B, uint64_t first_bit, uint64_t stride_bits, uint64_t *d_total_bits,
+                       hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_layout_kernel, dim3(1), dim3(EMIT_NT), 0, stream, B, first_bit, stride_bits, d_total_bits);
+}
+
+void bzx_launch_stream_frame(const BzxBatch &B, int level, const uint64_t *d_total_bits, uint64_t *d_out_bytes,
+                             hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_stream_frame_kernel, dim3(1), dim3(64), 0, stream, B, level, d_total_bits, d_out_bytes);
+}

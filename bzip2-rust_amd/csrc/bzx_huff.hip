@@ -1,0 +1,340 @@
+// bzx_huff.hip -- multi-table Huffman optimisation of one block's symbol stream on gfx950.
+//
+// Contract (reference src/huffman_coding/huffman.rs:79-374, huf_encode up to the point where
+// bits are written): number of tables from nMTF (huffman.rs:87-93), initial tables from the
+// symbol histogram (huffman.rs:472-532 -- libbz2's partition rule), four passes
+// of { cost of every 50-symbol group under each table, first-minimum table, per-table symbol
+// frequencies, new code lengths } (huffman.rs:114-200), selector MTF (huffman.rs:237-292),
+// canonical codes (huffman.rs:361-374).  Code lengths come from a literal restatement of
+// libbz2's heap construction (replaces huffman_code_from_weights.rs:17-84),
+// run by one lane per table, because its tie-breaking decides output bits.
+//
+// Parallel shape: one workgroup per block; one lane per 50-symbol group (<= 18002 groups);
+// six 10-bit code-length fields packed in two LDS words per symbol so a group cost is 50 x 2
+// LDS reads; rfreq in LDS atomics.  Also produces every section size so the emitter and the
+// stream layout know all bit offsets.
+#include <hip/hip_runtime.h>
+#include "bzx_device.h"
+#include "bzx_wg.h"
+
+#define HUF_NT 512
+#define HUF_NW (HUF_NT / 64)
+
+__shared__ uint32_t h_freq[BZX_MAX_ALPHA + 2];
+__shared__ uint8_t h_len[6][BZX_MAX_ALPHA + 2];
+__shared__ uint32_t h_lenA[BZX_MAX_ALPHA + 2];   // len0 | len1<<10 | len2<<20
+__shared__ uint32_t h_lenB[BZX_MAX_ALPHA + 2];   // len3 | len4<<10 | len5<<20
+__shared__ uint32_t h_rfreq[6][BZX_MAX_ALPHA + 2];
+__shared__ int32_t h_heap[6][BZX_MAX_ALPHA + 2];
+__shared__ int32_t h_weight[6][BZX_MAX_ALPHA * 2];
+__shared__ int32_t h_parent[6][BZX_MAX_ALPHA * 2];
+__shared__ uint32_t h_code[6][BZX_MAX_ALPHA + 2];
+__shared__ uint32_t h_part[6][2];   // initial partition [gs, ge] per table
+__shared__ uint32_t h_scratch[2 * HUF_NW];
+__shared__ uint32_t h_bcast[4];
+__shared__ uint32_t h_acc[4];       // [0] selector bits, [1] table bits, [2] payload bits
+
+// libbz2 hbMakeCodeLengths for table t (one lane).
+__device__ void make_code_lengths(int t, int32_t alpha, int32_t max_len)
+{
+    int32_t *heap = h_heap[t], *weight = h_weight[t], *parent = h_parent[t];
+    for (int32_t i = 0; i < alpha; i++) {
+        const uint32_t f = h_rfreq[t][i];
+        weight[i + 1] = (int32_t)((f == 0 ? 1u : f) << 8);
+    }
+    for (;;) {
+        int32_t n_nodes = alpha, n_heap = 0;
+        heap[0] = 0;
+        weight[0] = 0;
+        parent[0] = -2;
+        for (int32_t i = 1; i <= alpha; i++) {
+            parent[i] = -1;
+            n_heap++;
+            heap[n_heap] = i;
+            int32_t zz = n_heap;
+            const int32_t tmp = heap[zz], wt = weight[tmp];
+            while (wt < weight[heap[zz >> 1]]) {
+                heap[zz] = heap[zz >> 1];
+                zz >>= 1;
+            }
+            heap[zz] = tmp;
+        }
+        while (n_heap > 1) {
+            int32_t n12[2];
+            for (int rep = 0; rep < 2; rep++) {
+                n12[rep] = heap[1];
+                heap[1] = heap[n_heap];
+                n_heap--;
+                int32_t zz = 1;
+                const int32_t tmp = heap[zz], wt = weight[tmp];
+                for (;;) {
+                    int32_t yy = zz << 1;
+                    if (yy > n_heap) break;
+                    if (yy < n_heap && weight[heap[yy + 1]] < weight[heap[yy]]) yy++;
+                    if (wt < weight[heap[yy]]) break;
+                    heap[zz] = heap[yy];
+                    zz = yy;
+                }
+                heap[zz] = tmp;
+            }
+            n_nodes++;
+            parent[n12[0]] = parent[n12[1]] = n_nodes;
+            const uint32_t w1 = (uint32_t)weight[n12[0]], w2 = (uint32_t)weight[n12[1]];
+            const uint32_t d1 = w1 & 0xffu, d2 = w2 & 0xffu;
+            weight[n_nodes] = (int32_t)(((w1 & 0xffffff00u) + (w2 & 0xffffff00u)) | (1u + (d1 > d2 ? d1 : d2)));
+            parent[n_nodes] = -1;
+            n_heap++;
+            heap[n_heap] = n_nodes;
+            int32_t zz = n_heap;
+            const int32_t tmp = heap[zz], wt = weight[tmp];
+            while (wt < weight[heap[zz >> 1]]) {
+                heap[zz] = heap[zz >> 1];
+                zz >>= 1;
+            }
+            heap[zz] = tmp;
+        }
+        bool too_long = false;
+        for (int32_t i = 1; i <= alpha; i++) {
+            int32_t j = 0, k = i;
+            while (parent[k] >= 0) {
+                k = parent[k];
+                j++;
+            }
+            h_len[t][i - 1] = (uint8_t)j;
+            if (j > max_len) too_long = true;
+        }
+        if (!too_long) break;
+        for (int32_t i = 1; i <= alpha; i++) {
+            int32_t j = weight[i] >> 8;
+            j = 1 + (j / 2);
+            weight[i] = j << 8;
+        }
+    }
+}
+
+__global__ __launch_bounds__(HUF_NT) void bzx_huff_kernel(BzxBatch B)
+{
+    const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
+
+    for (;;) {
+        if (tid == 0) h_bcast[0] = atomicAdd(&B.counters[2], 1u);
+        __syncthreads();
+        const uint32_t b = h_bcast[0];
+        __syncthreads();
+        if (b >= B.nblk) break;
+
+        const uint32_t n_mtf = B.blk[b].n_mtf;
+        const uint32_t alpha = B.blk[b].n_in_use + 2;
+        const uint16_t *__restrict__ V = B.mtfv + (size_t)b * BZX_BLK_STRIDE;
+        uint8_t *__restrict__ SEL = B.selector + (size_t)b * BZX_SEL_STRIDE;
+        uint8_t *__restrict__ SELM = B.selector_mtf + (size_t)b * BZX_SEL_STRIDE;
+        uint16_t *__restrict__ GB = B.gbits + (size_t)b * BZX_SEL_STRIDE;
+        const uint32_t n_sel = (n_mtf + BZX_G_SIZE - 1) / BZX_G_SIZE;
+        const uint32_t n_groups = n_mtf < 200 ? 2u : n_mtf < 600 ? 3u : n_mtf < 1200 ? 4u : n_mtf < 2400 ? 5u : 6u;
+
+        for (uint32_t i = tid; i < BZX_MAX_ALPHA + 2; i += HUF_NT) h_freq[i] = i < alpha ? B.freq[(size_t)b * 260 + i] : 0u;
+        if (tid < 4) h_acc[tid] = 0;
+        __syncthreads();
+
+        // ---- initial tables (libbz2 partition rule)
+        if (tid == 0) {
+            int32_t n_part = (int32_t)n_groups, rem_f = (int32_t)n_mtf, gs = 0;
+            while (n_part > 0) {
+                const int32_t t_freq = rem_f / n_part;
+                int32_t ge = gs - 1, a_freq = 0;
+                while (a_freq < t_freq && ge < (int32_t)alpha - 1) {
+                    ge++;
+                    a_freq += (int32_t)h_freq[ge];
+                }
+                if (ge > gs && n_part != (int32_t)n_groups && n_part != 1 && (((int32_t)n_groups - n_part) % 2 == 1)) {
+                    a_freq -= (int32_t)h_freq[ge];
+                    ge--;
+                }
+                h_part[n_part - 1][0] = (uint32_t)gs;
+                h_part[n_part - 1][1] = (uint32_t)ge;   // may be gs-1 (empty); stored as int bits
+                n_part--;
+                gs = ge + 1;
+                rem_f -= a_freq;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < 6 * (BZX_MAX_ALPHA + 2); i += HUF_NT) {
+            const uint32_t t = i / (BZX_MAX_ALPHA + 2), v = i % (BZX_MAX_ALPHA + 2);
+            uint8_t l = 15;
+            if (t < n_groups && (int32_t)v >= (int32_t)h_part[t][0] && (int32_t)v <= (int32_t)h_part[t][1]) l = 0;
+            h_len[t][v] = l;
+        }
+        __syncthreads();
+
+        // ---- four refinement passes
+        for (int iter = 0; iter < BZX_N_ITERS; iter++) {
+            for (uint32_t i = tid; i < 6 * (BZX_MAX_ALPHA + 2); i += HUF_NT) (&h_rfreq[0][0])[i] = 0;
+            for (uint32_t v = tid; v < BZX_MAX_ALPHA + 2; v += HUF_NT) {
+                h_lenA[v] = (uint32_t)h_len[0][v] | ((uint32_t)h_len[1][v] << 10) | ((uint32_t)h_len[2][v] << 20);
+                h_lenB[v] = (uint32_t)h_len[3][v] | ((uint32_t)h_len[4][v] << 10) | ((uint32_t)h_len[5][v] << 20);
+            }
+            __syncthreads();
+            for (uint32_t g = tid; g < n_sel; g += HUF_NT) {
+                const uint32_t gs = g * BZX_G_SIZE;
+                const uint32_t cnt = (n_mtf - gs < BZX_G_SIZE) ? n_mtf - gs : BZX_G_SIZE;
+                const uint32_t *__restrict__ vp = reinterpret_cast<const uint32_t *>(V + gs);
+                uint32_t sy[BZX_G_SIZE / 2];
+#pragma unroll
+                for (int k = 0; k < BZX_G_SIZE / 2; k++) sy[k] = vp[k];
+                uint32_t accA = 0, accB = 0;
+#pragma unroll
+                for (int k = 0; k < BZX_G_SIZE; k++) {
+                    if ((uint32_t)k < cnt) {
+                        const uint32_t s = (sy[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                        accA += h_lenA[s];
+                        accB += h_lenB[s];
+                    }
+                }
+                const uint32_t cost[6] = {accA & 1023u, (accA >> 10) & 1023u, (accA >> 20) & 1023u,
+                                          accB & 1023u, (accB >> 10) & 1023u, (accB >> 20) & 1023u};
+                uint32_t bc = 999999999u, bt = 0;
+#pragma unroll
+                for (uint32_t t = 0; t < 6; t++)
+                    if (t < n_groups && cost[t] < bc) {
+                        bc = cost[t];
+                        bt = t;
+                    }
+                SEL[g] = (uint8_t)bt;
+#pragma unroll
+                for (int k = 0; k < BZX_G_SIZE; k++) {
+                    if ((uint32_t)k < cnt) {
+                        const uint32_t s = (sy[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                        atomicAdd(&h_rfreq[bt][s], 1u);
+                    }
+                }
+            }
+            __syncthreads();
+            if (lane == 0 && wave < n_groups) make_code_lengths((int)wave, (int32_t)alpha, 17);
+            __syncthreads();
+        }
+
+        // ---- canonical codes (huffman.rs:361-374), one lane per table
+        if (lane == 0 && wave < n_groups) {
+            const int t = (int)wave;
+            int32_t min_len = 32, max_len = 0;
+            for (uint32_t i = 0; i < alpha; i++) {
+                const int32_t l = h_len[t][i];
+                if (l > max_len) max_len = l;
+                if (l < min_len) min_len = l;
+            }
+            uint32_t vec = 0;
+            for (int32_t nn = min_len; nn <= max_len; nn++) {
+                for (uint32_t i = 0; i < alpha; i++)
+                    if (h_len[t][i] == nn) h_code[t][i] = vec++;
+                vec <<= 1;
+            }
+            // coding-table section size: 5 + sum(2|delta| + 1)
+            uint32_t bits = 5;
+            int32_t curr = h_len[t][0];
+            for (uint32_t i = 0; i < alpha; i++) {
+                const int32_t l = h_len[t][i];
+                bits += 2u * (uint32_t)(l > curr ? l - curr : curr - l) + 1u;
+                curr = l;
+            }
+            atomicAdd(&h_acc[1], bits);
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < 6 * 260; i += HUF_NT) {
+            const uint32_t t = i / 260, v = i % 260;
+            const bool live = t < n_groups && v < alpha;
+            B.len[(size_t)b * 6 * 260 + i] = live ? h_len[t][v] : (uint8_t)0;
+            B.code[(size_t)b * 6 * 260 + i] = live ? h_code[t][v] : 0u;
+        }
+        for (uint32_t v = tid; v < BZX_MAX_ALPHA + 2; v += HUF_NT) {
+            h_lenA[v] = (uint32_t)h_len[0][v] | ((uint32_t)h_len[1][v] << 10) | ((uint32_t)h_len[2][v] << 20);
+            h_lenB[v] = (uint32_t)h_len[3][v] | ((uint32_t)h_len[4][v] << 10) | ((uint32_t)h_len[5][v] << 20);
+        }
+        __syncthreads();
+
+        // ---- payload size per group under its final selector; total payload bits
+        {
+            uint32_t my_bits = 0;
+            for (uint32_t g = tid; g < n_sel; g += HUF_NT) {
+                const uint32_t gs = g * BZX_G_SIZE;
+                const uint32_t cnt = (n_mtf - gs < BZX_G_SIZE) ? n_mtf - gs : BZX_G_SIZE;
+                const uint32_t *__restrict__ vp = reinterpret_cast<const uint32_t *>(V + gs);
+                const uint32_t bt = SEL[g];
+                uint32_t acc = 0;
+                for (uint32_t k = 0; k < BZX_G_SIZE / 2; k++) {
+                    const uint32_t w = vp[k];
+                    if (2 * k < cnt) acc += h_len[bt][w & 0xffffu];
+                    if (2 * k + 1 < cnt) acc += h_len[bt][w >> 16];
+                }
+                GB[g] = (uint16_t)acc;
+                my_bits += acc;
+            }
+            uint32_t tot;
+            (void)bzx_block_excl_sum<HUF_NT>(my_bits, h_scratch, tot);
+            if (tid == 0) h_acc[2] = tot;
+        }
+
+        // ---- selector MTF (huffman.rs:237-292): chunk per lane, start list rebuilt from earlier chunks
+        {
+            const uint32_t per = (n_sel + HUF_NT - 1) / HUF_NT;
+            const uint32_t lo = tid * per;
+            const uint32_t hi = lo + per < n_sel ? lo + per : n_sel;
+            // start list: symbols by most recent occurrence before lo, then never-seen ascending
+            uint8_t pos[6];
+            uint32_t cnt = 0, seen = 0;
+            for (uint32_t i = lo < n_sel ? lo : n_sel; i > 0 && cnt < n_groups;) {
+                i--;
+                const uint32_t s = SEL[i];
+                if (!((seen >> s) & 1u)) {
+                    seen |= 1u << s;
+                    pos[cnt++] = (uint8_t)s;
+                }
+            }
+            for (uint32_t s = 0; s < n_groups && cnt < n_groups; s++)
+                if (!((seen >> s) & 1u)) pos[cnt++] = (uint8_t)s;
+            uint32_t my_bits = 0;
+            for (uint32_t i = lo; i < hi; i++) {
+                const uint8_t ll = SEL[i];
+                uint32_t j = 0;
+                uint8_t tmp = pos[0];
+                while (ll != tmp) {
+                    j++;
+                    const uint8_t t2 = tmp;
+                    tmp = pos[j];
+                    pos[j] = t2;
+                }
+                pos[0] = tmp;
+                SELM[i] = (uint8_t)j;
+                my_bits += j + 1;
+            }
+            uint32_t tot;
+            (void)bzx_block_excl_sum<HUF_NT>(my_bits, h_scratch, tot);
+            if (tid == 0) h_acc[0] = tot;
+        }
+        __syncthreads();
+
+        if (tid == 0) {
+            uint32_t map_words = 0;
+            for (uint32_t i = 0; i < 16; i++) {
+                uint32_t any = 0;
+                for (uint32_t j = 0; j < 16; j++) any |= B.in_use[(size_t)b * 256 + i * 16 + j];
+                map_words += any ? 1u : 0u;
+            }
+            const uint32_t map_bits = 16 + 16 * map_words;
+            BzxBlock &d = B.blk[b];
+            d.n_groups = n_groups;
+            d.n_selectors = n_sel;
+            d.sec_bits[0] = h_acc[0];
+            d.sec_bits[1] = h_acc[1];
+            d.sec_bits[2] = h_acc[2];
+            d.sec_bits[3] = map_bits;
+            // 48 magic + 32 crc + 1 randomised + 24 origPtr = 105 ; 3 nGroups + 15 nSelectors
+            d.bits = 105ull + map_bits + 3 + 15 + h_acc[0] + h_acc[1] + h_acc[2];
+        }
+        __syncthreads();
+    }
+}
+
+void bzx_launch_huffman(const BzxBatch &B, uint32_t grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_huff_kernel, dim3(grid), dim3(HUF_NT), 0, stream, B);
+}

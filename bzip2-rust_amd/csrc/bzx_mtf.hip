@@ -1,0 +1,274 @@
+// bzx_mtf.hip -- move-to-front + zero-run (RUNA/RUNB) coding of the BWT last column on gfx950.
+//
+// Contract (reference src/tools/rle2_mtf.rs:23-177, rle2_mtf_encode): bytes in use -> dense
+// symbol ids; MTF rank of every byte; runs of rank 0 -> bijective base-2 digits RUNA(0)/RUNB(1);
+// other ranks -> rank+1; EOB = nInUse+1 appended; histogram of the EMITTED symbols incl. EOB
+// (libbz2 counting; the reference's freqs[] is mis-indexed).
+//
+// MTF is a serial recurrence over the block.  It is cut into up to 512 chunks (one lane each):
+// the MTF list at a chunk start is "symbols by most recent occurrence before the chunk", which
+// each lane rebuilds from the per-chunk recency lists of the chunks before it.  Then every lane
+// runs the plain MTF over its own chunk with its list in LDS.  Zero-run coding is a second,
+// fully parallel sweep over the rank bytes (max-scan for run starts, sum-scan for offsets).
+#include <hip/hip_runtime.h>
+#include "bzx_device.h"
+#include "bzx_wg.h"
+
+#define MTF_NT 512
+#define MTF_LIST_BYTES (72 * 1024)
+#define MTF_E 16
+
+__shared__ uint8_t m_rec[MTF_LIST_BYTES];    // per-chunk recency lists (most recent first)
+__shared__ uint8_t m_list[MTF_LIST_BYTES];   // per-chunk working MTF lists
+__shared__ uint16_t m_reccnt[MTF_NT];
+__shared__ uint32_t m_inuse[256];
+__shared__ uint8_t m_seq[256];
+__shared__ uint32_t m_freq[BZX_MAX_ALPHA + 2];
+__shared__ uint32_t m_scratch[2 * (MTF_NT / 64)];
+__shared__ uint32_t m_bcast[4];   // [0] block, [1] carry last-nonzero+1, [2] carry output count
+
+struct Seen256 {
+    uint64_t w0, w1, w2, w3;
+    __device__ __forceinline__ void clear() { w0 = w1 = w2 = w3 = 0; }
+    // returns true if s was already present; marks it
+    __device__ __forceinline__ bool test_set(uint32_t s)
+    {
+        const uint64_t bit = 1ull << (s & 63u);
+        uint64_t *w = s < 128u ? (s < 64u ? &w0 : &w1) : (s < 192u ? &w2 : &w3);
+        const bool was = (*w & bit) != 0;
+        *w |= bit;
+        return was;
+    }
+    __device__ __forceinline__ bool test(uint32_t s) const
+    {
+        const uint64_t w = s < 128u ? (s < 64u ? w0 : w1) : (s < 192u ? w2 : w3);
+        return (w >> (s & 63u)) & 1ull;
+    }
+};
+
+__global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
+{
+    const uint32_t tid = threadIdx.x;
+
+    for (;;) {
+        if (tid == 0) m_bcast[0] = atomicAdd(&B.counters[1], 1u);
+        __syncthreads();
+        const uint32_t b = m_bcast[0];
+        __syncthreads();
+        if (b >= B.nblk) break;
+
+        const uint32_t n = B.blk[b].n;
+        const uint8_t *__restrict__ L = B.bwt + (size_t)b * BZX_BLK_STRIDE;
+        uint8_t *__restrict__ R = B.rank + (size_t)b * BZX_BLK_STRIDE;
+        uint16_t *__restrict__ V = B.mtfv + (size_t)b * BZX_BLK_STRIDE;
+
+        // ---- 1. bytes in use -> dense ids (rle2_mtf.rs:26-45)
+        if (tid < 256) m_inuse[tid] = 0;
+        for (uint32_t i = tid; i < BZX_MAX_ALPHA + 2; i += MTF_NT) m_freq[i] = 0;
+        __syncthreads();
+        {
+            const uint32_t n16 = n & ~15u;
+            for (uint32_t i = tid * 16; i < n16; i += MTF_NT * 16) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(L + i);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) m_inuse[(w[q] >> (8 * k)) & 255u] = 1;
+            }
+            for (uint32_t i = n16 + tid; i < n; i += MTF_NT) m_inuse[L[i]] = 1;
+        }
+        __syncthreads();
+        uint32_t n_in_use;
+        {
+            const uint32_t flag = tid < 256 ? m_inuse[tid] : 0u;
+            const uint32_t ex = bzx_block_excl_sum<MTF_NT>(flag, m_scratch, n_in_use);
+            if (tid < 256) {
+                m_seq[tid] = (uint8_t)ex;
+                B.in_use[(size_t)b * 256 + tid] = (uint8_t)flag;
+            }
+        }
+        __syncthreads();
+
+        // ---- 2. chunking: at most 512 chunks, list stride = nInUse bytes, lists fit 72 KiB
+        uint32_t nch = MTF_LIST_BYTES / n_in_use;
+        if (nch > MTF_NT) nch = MTF_NT;
+        uint32_t csz = (n + nch - 1) / nch;
+        csz = (csz + 15u) & ~15u;
+        const uint32_t nch_used = (n + csz - 1) / csz;
+        const uint32_t stride = n_in_use;
+        const uint32_t c_lo = tid * csz;
+        const uint32_t c_hi = (c_lo + csz < n) ? c_lo + csz : n;
+        const bool have_chunk = tid < nch_used;
+
+        // ---- 3. recency list of my chunk: distinct symbols by last occurrence, most recent first
+        if (have_chunk) {
+            Seen256 seen;
+            seen.clear();
+            uint32_t cnt = 0;
+            uint8_t *rec = m_rec + tid * stride;
+            for (uint32_t i = c_hi; i > c_lo && cnt < n_in_use;) {
+                i--;
+                const uint32_t s = m_seq[L[i]];
+                if (!seen.test_set(s)) rec[cnt++] = (uint8_t)s;
+            }
+            m_reccnt[tid] = (uint16_t)cnt;
+        }
+        __syncthreads();
+
+        // ---- 4. MTF list at my chunk start: walk the earlier chunks backwards
+        if (have_chunk) {
+            Seen256 seen;
+            seen.clear();
+            uint32_t cnt = 0;
+            uint8_t *lst = m_list + tid * stride;
+            for (uint32_t c = tid; c > 0 && cnt < n_in_use;) {
+                c--;
+                const uint8_t *rec = m_rec + c * stride;
+                const uint32_t rc = m_reccnt[c];
+                for (uint32_t k = 0; k < rc; k++) {
+                    const uint32_t s = rec[k];
+                    if (!seen.test_set(s)) lst[cnt++] = (uint8_t)s;
+                }
+            }
+            // symbols never seen so far keep the initial (ascending) order
+            for (uint32_t s = 0; s < n_in_use && cnt < n_in_use; s++)
+                if (!seen.test(s)) lst[cnt++] = (uint8_t)s;
+        }
+        __syncthreads();
+
+        // ---- 5. plain MTF over my chunk (rle2_mtf.rs:61-138), rank bytes to HBM
+        if (have_chunk) {
+            uint8_t *lst = m_list + tid * stride;
+            uint32_t front = lst[0];
+            for (uint32_t i0 = c_lo; i0 < c_hi; i0 += 16) {
+                // csz is a multiple of 16 and slabs are 256-byte aligned: 16-byte loads/stores are aligned
+                const uint4 v = *reinterpret_cast<const uint4 *>(L + i0);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t i = i0 + q * 4 + k;
+                        if (i < c_hi) {
+                            const uint32_t s = m_seq[(w[q] >> (8 * k)) & 255u];
+                            uint32_t j = 0;
+                            if (s != front) {
+                                uint32_t tmp = front;
+                                do {
+                                    j++;
+                                    const uint32_t t2 = tmp;
+                                    tmp = lst[j];
+                                    lst[j] = (uint8_t)t2;
+                                } while (tmp != s);
+                                front = s;
+                            }
+                            o[q] |= j << (8 * k);
+                        }
+                    }
+                }
+                *reinterpret_cast<uint4 *>(R + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        __syncthreads();
+
+        // ---- 6. zero-run coding + symbol emission + histogram (rle2_mtf.rs:63-172)
+        if (tid == 0) {
+            m_bcast[1] = 0;
+            m_bcast[2] = 0;
+        }
+        __syncthreads();
+        for (uint32_t t0 = 0; t0 < n; t0 += MTF_NT * MTF_E) {
+            const uint32_t i0 = t0 + tid * MTF_E;
+            const uint32_t carry_p1 = m_bcast[1], carry_out = m_bcast[2];
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (i0 < n) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(R + i0);   // bytes past n are ignored below
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            }
+            // last nonzero position (+1) inside my 16 bytes
+            uint32_t my_p1 = 0;
+#pragma unroll
+            for (int k = 0; k < MTF_E; k++) {
+                const uint32_t i = i0 + k;
+                const uint32_t r = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+                if (i < n && r != 0) my_p1 = i + 1;
+            }
+            uint32_t dummy_s, dummy_t, p1_excl, p1_total;
+            bzx_block_scan_sum_max<MTF_NT>(0u, my_p1, m_scratch, dummy_s, dummy_t, p1_excl, p1_total);
+            const uint32_t p1_in = p1_excl ? p1_excl : carry_p1;
+            // count my output symbols
+            uint32_t p1 = p1_in, my_cnt = 0;
+#pragma unroll
+            for (int k = 0; k < MTF_E; k++) {
+                const uint32_t i = i0 + k;
+                const uint32_t r = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+                if (i < n && r != 0) {
+                    const uint32_t zr = i - p1;
+                    my_cnt += 1u + (zr ? 31u - (uint32_t)__clz(zr + 1u) : 0u);
+                    p1 = i + 1;
+                }
+            }
+            uint32_t cnt_total;
+            const uint32_t cnt_excl = bzx_block_excl_sum<MTF_NT>(my_cnt, m_scratch, cnt_total);
+            // emit
+            uint32_t o = carry_out + cnt_excl;
+            p1 = p1_in;
+#pragma unroll
+            for (int k = 0; k < MTF_E; k++) {
+                const uint32_t i = i0 + k;
+                const uint32_t r = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+                if (i < n && r != 0) {
+                    uint32_t zr = i - p1;
+                    if (zr) {
+                        zr--;
+                        for (;;) {
+                            const uint32_t sym = zr & 1u;
+                            V[o++] = (uint16_t)sym;
+                            atomicAdd(&m_freq[sym], 1u);
+                            if (zr < 2) break;
+                            zr = (zr - 2) >> 1;
+                        }
+                    }
+                    V[o++] = (uint16_t)(r + 1);
+                    atomicAdd(&m_freq[r + 1], 1u);
+                    p1 = i + 1;
+                }
+            }
+            if (tid == 0) {
+                if (p1_total) m_bcast[1] = p1_total;
+                m_bcast[2] = carry_out + cnt_total;
+            }
+            __syncthreads();
+        }
+        // trailing zero run + EOB
+        if (tid == 0) {
+            uint32_t o = m_bcast[2];
+            uint32_t zr = n - m_bcast[1];
+            if (zr) {
+                zr--;
+                for (;;) {
+                    const uint32_t sym = zr & 1u;
+                    V[o++] = (uint16_t)sym;
+                    m_freq[sym]++;
+                    if (zr < 2) break;
+                    zr = (zr - 2) >> 1;
+                }
+            }
+            const uint32_t eob = n_in_use + 1;
+            V[o++] = (uint16_t)eob;
+            m_freq[eob]++;
+            B.blk[b].n_mtf = o;
+            B.blk[b].n_in_use = n_in_use;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < 260; i += MTF_NT) B.freq[(size_t)b * 260 + i] = i < BZX_MAX_ALPHA ? m_freq[i] : 0u;
+        __syncthreads();
+    }
+}
+
+void bzx_launch_mtf(const BzxBatch &B, uint32_t grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_mtf_kernel, dim3(grid), dim3(MTF_NT), 0, stream, B);
+}

@@ -41,6 +41,16 @@ class BzxLib:
         L.bzx_ctx_destroy.argtypes = [C.c_void_p]
         L.bzx_stage_bwt.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32)]
+        L.bzx_stage_mtf.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32),
+                                    C.c_void_p, C.c_void_p]
+        L.bzx_stage_huffman.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
+        L.bzx_compress_block.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_char_p, C.c_size_t,
+                                         C.POINTER(C.c_size_t), C.POINTER(C.c_uint8)]
+        L.bzx_compress_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bzx_get_stats.argtypes = [C.c_void_p, C.POINTER(BzxStats)]
         self.ctx = C.c_void_p()
         self._check(L.bzx_ctx_create(device, max_blocks, C.byref(self.ctx)))
 
@@ -65,6 +75,58 @@ class BzxLib:
         return out.raw[:n], orig.value, status.value
 
 
+    def stage_mtf(self, bwt: bytes):
+        n = len(bwt)
+        mtfv = (C.c_uint16 * (n + 2))()
+        n_mtf = C.c_uint32()
+        freq = (C.c_uint32 * 258)()
+        in_use = (C.c_uint8 * 256)()
+        self._check(self.lib.bzx_stage_mtf(self.ctx, bwt, n, mtfv, C.byref(n_mtf), freq, in_use))
+        return list(mtfv[:n_mtf.value]), list(freq), bytes(in_use)
+
+    def stage_huffman(self, mtfv, freq, alpha):
+        n_mtf = len(mtfv)
+        arr = (C.c_uint16 * n_mtf)(*mtfv)
+        f = (C.c_uint32 * 258)(*freq)
+        ng = C.c_uint32()
+        ns = C.c_uint32()
+        sel = (C.c_uint8 * 18002)()
+        ln = (C.c_uint8 * (6 * 258))()
+        code = (C.c_uint32 * (6 * 258))()
+        self._check(self.lib.bzx_stage_huffman(self.ctx, arr, n_mtf, f, alpha, C.byref(ng), C.byref(ns), sel, ln, code))
+        lens = [list(ln[t * 258:t * 258 + alpha]) for t in range(ng.value)]
+        codes = [list(code[t * 258:t * 258 + alpha]) for t in range(ng.value)]
+        return ng.value, list(sel[:ns.value]), lens, codes
+
+    def compress_blocks(self, blocks, crcs):
+        """blocks: list of bytes (RLE1'd), crcs: list of int -> list of (image bytes, pad_bits)."""
+        nb = len(blocks)
+        caps = [len(b) + len(b) // 50 + 1024 for b in blocks]
+        outs = [C.create_string_buffer(c) for c in caps]
+        p_in = (C.c_char_p * nb)(*blocks)
+        p_ns = (C.c_size_t * nb)(*[len(b) for b in blocks])
+        p_crc = (C.c_uint32 * nb)(*crcs)
+        p_out = (C.c_void_p * nb)(*[C.addressof(o) for o in outs])
+        p_cap = (C.c_size_t * nb)(*caps)
+        p_len = (C.c_size_t * nb)()
+        p_pad = (C.c_uint8 * nb)()
+        self._check(self.lib.bzx_compress_blocks(self.ctx, nb, p_in, p_ns, p_crc, p_out, p_cap, p_len, p_pad))
+        return [(outs[i].raw[:p_len[i]], p_pad[i]) for i in range(nb)]
+
+    def compress_block(self, blk: bytes, crc: int):
+        return self.compress_blocks([blk], [crc])[0]
+
+    def stats(self):
+        st = BzxStats()
+        self._check(self.lib.bzx_get_stats(self.ctx, C.byref(st)))
+        return st
+
+
+class OracleHuff(C.Structure):
+    _fields_ = [("n_groups", C.c_int32), ("n_selectors", C.c_int32), ("selector", C.c_uint8 * 18002),
+                ("selector_mtf", C.c_uint8 * 18002), ("len", (C.c_uint8 * 258) * 6), ("code", (C.c_int32 * 258) * 6)]
+
+
 class Oracle:
     def __init__(self, path=ORACLE_PATH):
         self.lib = L = C.CDLL(path)
@@ -75,6 +137,41 @@ class Oracle:
         L.bzo_compress_buffer.restype = C.c_size_t
         L.bzo_compress_buffer.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t,
                                           C.POINTER(C.c_int32)]
+
+    def mtf(self, bwt: bytes):
+        n = len(bwt)
+        mtfv = (C.c_uint16 * (n + 2))()
+        freq = (C.c_int32 * 258)()
+        in_use = (C.c_uint8 * 256)()
+        niu = C.c_int32()
+        self.lib.bzo_mtf_rle2.restype = C.c_int32
+        m = self.lib.bzo_mtf_rle2(bwt, n, mtfv, freq, in_use, C.byref(niu))
+        return list(mtfv[:m]), list(freq), bytes(in_use), niu.value
+
+    def huff(self, mtfv, freq, alpha):
+        T = OracleHuff()
+        arr = (C.c_uint16 * len(mtfv))(*mtfv)
+        f = (C.c_int32 * 258)(*freq)
+        self.lib.bzo_huff_optimise(arr, len(mtfv), f, alpha, C.byref(T))
+        lens = [list(T.len[t][:alpha]) for t in range(T.n_groups)]
+        codes = [list(T.code[t][:alpha]) for t in range(T.n_groups)]
+        return T.n_groups, list(T.selector[:T.n_selectors]), lens, codes
+
+    def crc32(self, data: bytes):
+        self.lib.bzo_crc32.restype = C.c_uint32
+        self.lib.bzo_crc32.argtypes = [C.c_char_p, C.c_size_t]
+        return self.lib.bzo_crc32(data, len(data))
+
+    def compress_block(self, blk: bytes, crc: int):
+        cap = len(blk) + len(blk) // 50 + 1024
+        out = C.create_string_buffer(cap)
+        ol = C.c_size_t()
+        pad = C.c_uint8()
+        self.lib.bzo_compress_block.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_char_p, C.c_size_t,
+                                                C.POINTER(C.c_size_t), C.POINTER(C.c_uint8)]
+        rc = self.lib.bzo_compress_block(blk, len(blk), crc, out, cap, C.byref(ol), C.byref(pad))
+        assert rc == 0
+        return out.raw[:ol.value], pad.value
 
     def bwt(self, blk: bytes):
         n = len(blk)

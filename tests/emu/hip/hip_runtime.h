@@ -178,3 +178,7 @@ inline void launch_kernel(void (*k)(P...), dim3 grid, dim3 block, A... a)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch_kernel(kernel, dim3(grid), dim3(block), ##__VA_ARGS__)
 template <typename F> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, F, int, size_t) { *n = 1; return 0; }
+struct uint4 { unsigned x, y, z, w; };
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r = {x, y, z, w}; return r; }
+struct uint2 { unsigned x, y; };
+inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r = {x, y}; return r; }
