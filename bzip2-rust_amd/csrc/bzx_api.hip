@@ -22,7 +22,10 @@ void bzx_launch_layout(const BzxBatch &B, uint64_t first_bit, uint64_t stride_bi
                        hipStream_t stream);
 void bzx_launch_stream_frame(const BzxBatch &B, int level, const uint64_t *d_total_bits, uint64_t *d_out_bytes,
                              hipStream_t stream);
-int bzx_split_device(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t *nblk_out);
+int bzx_split_launch_boundaries(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t max_blocks,
+                                BzxSplitWs *ws_out);
+void bzx_split_launch_scatter(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, const BzxSplitWs &ws,
+                              uint32_t nblk, uint8_t *d_slabs, BzxBlock *d_blk);
 uint32_t bzx_bwt_max_blocks_per_cu();
 
 struct bzx_ctx {
@@ -262,9 +265,20 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_outbuf, 0, (size_t)nblk * BZX_OUT_STRIDE, ctx->stream));
             if (nblk) bzx_launch_emit(B, grid_for(ctx, nblk, 2), ctx->stream);
         } else {
+            // sizes are known after the Huffman stage: lay the stream out, check it fits, then emit
             B.out = (uint32_t *)d_stream_out;
             bzx_launch_layout(B, 32, 0, ctx->d_scalars, ctx->stream);
-            HIP_TRY(ctx, hipMemsetAsync(d_stream_out, 0, stream_cap, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                        ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            const uint64_t out_bytes = (ctx->h_scalars[0] + 80 + 7) >> 3;
+            const uint64_t need = (out_bytes + 3) & ~3ull;
+            ctx->h_scalars[1] = out_bytes;
+            if (need > stream_cap) {
+                ctx->err = "output buffer too small for the compressed stream";
+                return BZX_E_OUTBUF;
+            }
+            HIP_TRY(ctx, hipMemsetAsync(d_stream_out, 0, need, ctx->stream));
             if (nblk) bzx_launch_emit(B, grid_for(ctx, nblk, 2), ctx->stream);
             bzx_launch_stream_frame(B, out_level, ctx->d_scalars, ctx->d_scalars + 1, ctx->stream);
         }
@@ -273,6 +287,24 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
     HIP_TRY(ctx, hipGetLastError());
     return BZX_OK;
 }
+
+int bzx_ctx_split_scratch(bzx_ctx *ctx, size_t bytes, void **p)
+{
+    if (bytes > ctx->split_ws_bytes) {
+        if (ctx->split_ws) (void)hipFree(ctx->split_ws);
+        ctx->split_ws = nullptr;
+        ctx->split_ws_bytes = 0;
+        if (hipMalloc(&ctx->split_ws, bytes) != hipSuccess) {
+            ctx->err = "hipMalloc(split scratch) failed";
+            return BZX_E_NOMEM;
+        }
+        ctx->split_ws_bytes = bytes;
+    }
+    *p = ctx->split_ws;
+    return BZX_OK;
+}
+hipStream_t bzx_ctx_stream(bzx_ctx *ctx) { return ctx->stream; }
+int bzx_ctx_ncu(bzx_ctx *ctx) { return ctx->n_cu; }
 
 static void collect_stage_times(bzx_ctx *ctx)
 {
@@ -471,4 +503,138 @@ extern "C" int bzx_compress_block(bzx_ctx *ctx, const uint8_t *blk, size_t n, ui
                                   size_t *out_len, uint8_t *pad_bits)
 {
     return bzx_compress_blocks(ctx, 1, &blk, &n, &crc, &out, &cap, out_len, pad_bits);
+}
+
+static int level_ok(int level) { return level >= 1 && level <= 9; }
+
+// Device split: raw (device) -> block slabs + descriptors (n, crc, in_off).  Returns the block count.
+static int split_on_device(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t *nblk_out)
+{
+    *nblk_out = 0;
+    if (len == 0) return BZX_OK;
+    const size_t nmax = (size_t)100000 * level - 19;
+    const size_t max_blocks_sz = (len + len / 4) / nmax + 2;
+    if (max_blocks_sz > 0x7fffffffu) return BZX_E_PARAM;
+    const uint32_t max_blocks = (uint32_t)max_blocks_sz;
+    int rc = ensure_blocks(ctx, max_blocks);
+    if (rc) return rc;
+    BzxSplitWs ws;
+    if ((rc = bzx_split_launch_boundaries(ctx, d_raw, len, level, max_blocks, &ws))) return rc;
+    uint32_t *h_n = (uint32_t *)(ctx->h_scalars + 4);
+    HIP_TRY(ctx, hipMemcpyAsync(h_n, ws.nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t nblk = *h_n;
+    if (nblk == 0 || nblk > max_blocks) {
+        ctx->err = "device block splitter produced an impossible block count";
+        return BZX_E_HIP;
+    }
+    bzx_split_launch_scatter(ctx, d_raw, len, ws, nblk, ctx->d_in, ctx->B.blk);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->B.in = ctx->d_in;
+    *nblk_out = nblk;
+    return BZX_OK;
+}
+
+static void fill_stats_from_blocks(bzx_ctx *ctx, uint32_t nblk, uint64_t raw_bytes)
+{
+    bzx_stats &st = ctx->stats;
+    st.nblk = nblk;
+    st.n_periodic = 0;
+    st.raw_bytes = raw_bytes;
+    st.rle1_bytes = 0;
+    st.mtf_symbols = 0;
+    for (uint32_t b = 0; b < nblk; b++) {
+        const BzxBlock &d = ctx->h_blk[b];
+        st.n_periodic += (d.status & BZX_ST_PERIODIC) ? 1 : 0;
+        st.rle1_bytes += d.n;
+        st.mtf_symbols += d.n_mtf;
+    }
+}
+
+extern "C" int bzx_compress_device(bzx_ctx *ctx, const void *d_raw, size_t len, int level, void *d_out, size_t cap,
+                                   size_t *out_len)
+{
+    if (!ctx || !d_out || !out_len || !level_ok(level) || (len && !d_raw)) return BZX_E_PARAM;
+    if (((uintptr_t)d_raw & 15u) || ((uintptr_t)d_out & 3u) || cap < 16) return BZX_E_PARAM;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    uint32_t nblk = 0;
+    int rc = split_on_device(ctx, (const uint8_t *)d_raw, len, level, &nblk);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    if ((rc = run_stages(ctx, nblk, STG_ALL, level, d_out, cap & ~(size_t)3))) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    if (nblk) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_blk, ctx->B.blk, nblk * sizeof(BzxBlock), hipMemcpyDeviceToHost,
+                                          ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out_len = (size_t)ctx->h_scalars[1];
+    collect_stage_times(ctx);
+    fill_stats_from_blocks(ctx, nblk, len);
+    ctx->stats.out_bits = (uint64_t)*out_len * 8;
+    (void)hipEventElapsedTime(&ctx->stats.ms_split, ctx->ev[5], ctx->ev[6]);
+    (void)hipEventElapsedTime(&ctx->stats.ms_total, ctx->ev[5], ctx->ev[7]);
+    return BZX_OK;
+}
+
+extern "C" int bzx_compress_buffer(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level, uint8_t *out, size_t cap,
+                                   size_t *out_len)
+{
+    if (!ctx || !out || !out_len || !level_ok(level) || (len && !raw)) return BZX_E_PARAM;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *d_raw = nullptr, *d_out = nullptr;
+    const size_t dcap = len + len / 4 + 8192;   // worst case: every block expands by 1% + 600 after RLE1's 25%
+    if (hipMalloc(&d_raw, len ? len : 16) != hipSuccess) return BZX_E_NOMEM;
+    if (hipMalloc(&d_out, dcap) != hipSuccess) {
+        (void)hipFree(d_raw);
+        return BZX_E_NOMEM;
+    }
+    int rc = BZX_OK;
+    size_t ol = 0;
+    if (len && hipMemcpyAsync(d_raw, raw, len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = BZX_E_HIP;
+    if (!rc) rc = bzx_compress_device(ctx, d_raw, len, level, d_out, dcap, &ol);
+    if (!rc) {
+        *out_len = ol;
+        if (ol > cap) rc = BZX_E_OUTBUF;
+        else if (hipMemcpy(out, d_out, ol, hipMemcpyDeviceToHost) != hipSuccess) rc = BZX_E_HIP;
+    }
+    (void)hipFree(d_raw);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+extern "C" int bzx_split_rle1(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level, uint8_t *blocks_out,
+                              uint32_t nblk_cap, uint32_t *ns, uint32_t *crcs, uint32_t *nblk_out)
+{
+    if (!ctx || !blocks_out || !ns || !crcs || !nblk_out || !level_ok(level) || (len && !raw)) return BZX_E_PARAM;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *nblk_out = 0;
+    if (len == 0) return BZX_OK;
+    void *d_raw = nullptr;
+    if (hipMalloc(&d_raw, len) != hipSuccess) return BZX_E_NOMEM;
+    int rc = BZX_OK;
+    uint32_t nblk = 0;
+    if (hipMemcpyAsync(d_raw, raw, len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = BZX_E_HIP;
+    if (!rc) rc = split_on_device(ctx, (const uint8_t *)d_raw, len, level, &nblk);
+    if (!rc && nblk > nblk_cap) rc = BZX_E_OUTBUF;
+    if (!rc) {
+        if (hipMemcpyAsync(ctx->h_blk, ctx->B.blk, nblk * sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = BZX_E_HIP;
+    }
+    for (uint32_t b = 0; !rc && b < nblk; b++) {
+        ns[b] = ctx->h_blk[b].n;
+        crcs[b] = ctx->h_blk[b].crc;
+        if (ns[b] == 0 || ns[b] > BZX_MAX_BLOCK) {
+            ctx->err = "device block splitter produced an impossible block length";
+            rc = BZX_E_HIP;
+            break;
+        }
+        if (hipMemcpy(blocks_out + (size_t)b * BZX_MAX_BLOCK, ctx->d_in + (size_t)b * BZX_BLK_STRIDE, ns[b],
+                      hipMemcpyDeviceToHost) != hipSuccess)
+            rc = BZX_E_HIP;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_raw);
+    if (!rc) *nblk_out = nblk;
+    return rc;
 }

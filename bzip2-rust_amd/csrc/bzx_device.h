@@ -71,3 +71,14 @@ struct BzxBatch {
 
 #define BZX_MTF_WS (72u * 1024u)
 #define BZX_OUT_STRIDE 921600u      // per-block output slab for the per-block entry points (bytes)
+
+// Scratch of the RLE1 / block splitter (bzx_rle1.hip).
+struct BzxSplitWs {
+    uint64_t *tile_rs;     // [ntiles+1] A: last run start (+1) inside the tile / after S1: carry-in run start (+1)
+    uint64_t *tile_off;    // [ntiles+1] B: emitted bytes / after S2: exclusive prefix F(tile start); [ntiles] = F(len)
+    uint64_t *blk_raw;     // [max_blocks+1] raw start of every block; [nblk] = len
+    uint64_t *blk_f;       // [max_blocks+1] F at the block start
+    uint32_t *nblk;        // [1]
+    uint32_t max_blocks;
+};
+

@@ -1,0 +1,521 @@
+// bzx_rle1.hip -- RLE1, block splitting and block CRCs of a whole raw buffer on gfx950.
+//
+// Contract (reference src/tools/rle1.rs:33-263 RLE1Block + src/tools/crc.rs:15-22 do_crc):
+// raw stream -> blocks of RLE1'd bytes (runs of 4..255 equal bytes -> 4 bytes + count) of at
+// most 100000*level-19(+4+5) bytes, each with the CRC-32/BZIP2 of the raw bytes it covers.
+// The split rule is libbz2's: the raw stream is cut into PIECES (maximal runs,
+// cut every 255 bytes); a block is a whole number of pieces and ends with the first piece that
+// brings its RLE1 length to >= nblockMAX; the pending run moves to the next block whole.
+//
+// The reference does this byte-serially under a lock (compress.rs:125-128).  Here:
+//   A  per 8 KiB tile: last run start                      -> scan S1 (tile run-start carry-in)
+//   B  per tile: RLE1 bytes emitted by the tile            -> scan S2 (tile RLE1 offsets F)
+//      position p with k = (p - runstart(p)) mod 255 emits  k<3: 1 byte, k==3: 2 bytes (the 4th
+//      copy + the count), k>3: nothing -- purely local once the run start is known.
+//   C  block boundaries: a short serial chain over blocks (one workgroup): smallest position x
+//      with F(x) >= F(start)+nblockMAX by search over the tile offsets and one tile scan, then
+//      the end of the piece containing x.
+//   D  per tile: scatter the emitted bytes into the block slabs (count byte = piece length - 4
+//      by a <= 251 byte look-ahead)
+//   E  per block: CRC of its raw range: per-lane table CRC of a chunk from a zero register,
+//      combined with x^(8*len) mod P multiplications (GF(2) polynomial arithmetic).
+#include <hip/hip_runtime.h>
+#include "bzx_device.h"
+#include "bzx_wg.h"
+
+#define RL_NT 256
+#define RL_BYTES 32
+#define RL_TILE (RL_NT * RL_BYTES)   // 8192
+
+// Per-lane view of 32 consecutive raw bytes of a tile.
+struct TileLane {
+    uint32_t w[8];         // the bytes
+    uint64_t p0;           // raw position of byte 0
+    uint32_t nvalid;       // bytes inside the input
+    uint32_t prev;         // byte before p0 (256 if p0 == 0)
+};
+
+__device__ __forceinline__ void tile_load(const uint8_t *__restrict__ raw, uint64_t len, uint64_t tile, TileLane &t)
+{
+    t.p0 = tile * RL_TILE + (uint64_t)threadIdx.x * RL_BYTES;
+    t.nvalid = t.p0 >= len ? 0u : (len - t.p0 < RL_BYTES ? (uint32_t)(len - t.p0) : (uint32_t)RL_BYTES);
+#pragma unroll
+    for (int i = 0; i < 8; i++) t.w[i] = 0;
+    if (t.nvalid == RL_BYTES) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(raw + t.p0);
+        const uint4 b = *reinterpret_cast<const uint4 *>(raw + t.p0 + 16);
+        t.w[0] = a.x; t.w[1] = a.y; t.w[2] = a.z; t.w[3] = a.w;
+        t.w[4] = b.x; t.w[5] = b.y; t.w[6] = b.z; t.w[7] = b.w;
+    } else {
+        for (uint32_t i = 0; i < t.nvalid; i++) t.w[i >> 2] |= (uint32_t)raw[t.p0 + i] << (8 * (i & 3));
+    }
+    t.prev = (t.p0 == 0 || t.nvalid == 0) ? 256u : raw[t.p0 - 1];
+}
+
+__device__ __forceinline__ uint32_t tile_byte(const TileLane &t, int i) { return (t.w[i >> 2] >> (8 * (i & 3))) & 255u; }
+
+// last run start (+1) among my bytes, 0 if none
+__device__ __forceinline__ uint64_t lane_last_rs(const TileLane &t)
+{
+    uint64_t rs = 0;
+    uint32_t prev = t.prev;
+#pragma unroll
+    for (int i = 0; i < RL_BYTES; i++) {
+        const uint32_t c = tile_byte(t, i);
+        if ((uint32_t)i < t.nvalid && c != prev) rs = t.p0 + i + 1;
+        prev = c;
+    }
+    return rs;
+}
+
+// Block-wide exclusive max scan of 64-bit values (0 = identity).  scratch: RL_NT/64 words.
+__device__ __forceinline__ uint64_t block_excl_max64(uint64_t v, uint64_t *scratch, uint64_t &total)
+{
+    const uint32_t lane = bzx_lane(), wave = bzx_wave();
+    uint64_t x = v;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint64_t y = __shfl_up(x, d);
+        if (lane >= d && y > x) x = y;
+    }
+    uint64_t ex = __shfl_up(x, 1);
+    if (lane == 0) ex = 0;
+    if (lane == 63) scratch[wave] = x;
+    __syncthreads();
+    uint64_t pre = 0, tot = 0;
+    for (uint32_t i = 0; i < RL_NT / 64; i++) {
+        const uint64_t s = scratch[i];
+        if (i < wave && s > pre) pre = s;
+        if (s > tot) tot = s;
+    }
+    __syncthreads();
+    total = tot;
+    return ex > pre ? ex : pre;
+}
+
+// ---- A: last run start per tile
+__global__ __launch_bounds__(RL_NT) void bzx_rl_runstart_kernel(const uint8_t *__restrict__ raw, uint64_t len,
+                                                                uint64_t ntiles, BzxSplitWs ws)
+{
+    __shared__ uint64_t scratch[RL_NT / 64];
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        TileLane t;
+        tile_load(raw, len, tile, t);
+        uint64_t tot;
+        (void)block_excl_max64(lane_last_rs(t), scratch, tot);
+        if (threadIdx.x == 0) ws.tile_rs[tile] = tot;
+    }
+}
+
+// ---- S1 / S2: single-workgroup exclusive scans over the tile summaries
+__global__ __launch_bounds__(1024) void bzx_rl_scan_kernel(uint64_t *v, uint64_t n, int is_max)
+{
+    // v[0..n) -> exclusive scan in place; v[n] = total
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry_s;
+    const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint64_t i0 = 0; i0 < n; i0 += 1024) {
+        const uint64_t i = i0 + tid;
+        const uint64_t x0 = i < n ? v[i] : 0ull;
+        uint64_t x = x0;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint64_t y = __shfl_up(x, d);
+            if (lane >= d) x = is_max ? (y > x ? y : x) : x + y;
+        }
+        uint64_t ex = __shfl_up(x, 1);
+        if (lane == 0) ex = 0;
+        if (lane == 63) wsum[wave] = x;
+        const uint64_t carry = carry_s;
+        __syncthreads();
+        uint64_t pre = 0, tot = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            const uint64_t s = wsum[w];
+            if (is_max) {
+                if (w < wave && s > pre) pre = s;
+                if (s > tot) tot = s;
+            } else {
+                if (w < wave) pre += s;
+                tot += s;
+            }
+        }
+        uint64_t r;
+        if (is_max) {
+            r = ex > pre ? ex : pre;
+            if (carry > r) r = carry;
+        } else {
+            r = carry + pre + ex;
+        }
+        if (i < n) v[i] = r;
+        __syncthreads();
+        if (tid == 0) carry_s = is_max ? (tot > carry ? tot : carry) : carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) v[n] = carry_s;
+}
+
+// Emission analysis of my 32 bytes: e[i] in {0,1,2} packed 2 bits each; returns my emitted byte count.
+// rs_in = run start (+1) carried into the tile (0 = none, only possible at p == 0).
+__device__ __forceinline__ uint32_t lane_emission(const TileLane &t, uint64_t rs_in_plus1, uint64_t &e_bits,
+                                                  uint32_t &k_first)
+{
+    // run start for my first byte: either inside earlier lanes of the tile / earlier tiles (rs_in) or my own byte
+    uint32_t k = 0;
+    if (t.nvalid) {
+        const uint64_t rs = rs_in_plus1 ? rs_in_plus1 - 1 : 0;   // p0 == 0 has rs_in == 0 and starts a run itself
+        k = (uint32_t)((t.p0 - rs) % 255u);
+    }
+    uint32_t prev = t.prev, cnt = 0;
+    uint64_t bits = 0;
+    k_first = k;
+#pragma unroll
+    for (int i = 0; i < RL_BYTES; i++) {
+        const uint32_t c = tile_byte(t, i);
+        if ((uint32_t)i < t.nvalid) {
+            if (c != prev) k = 0;
+            if (i == 0) k_first = k;
+            const uint32_t e = k < 3 ? 1u : (k == 3 ? 2u : 0u);
+            bits |= (uint64_t)e << (2 * i);
+            cnt += e;
+            k = (k + 1 == 255) ? 0 : k + 1;
+        }
+        prev = c;
+    }
+    e_bits = bits;
+    return cnt;
+}
+
+// Shared tile analysis: every lane gets its bytes, emission bits and F (RLE1 offset, tile relative) of its first byte.
+struct TileInfo {
+    TileLane t;
+    uint64_t e_bits;
+    uint32_t k_first;
+    uint32_t f_excl;     // emitted bytes of the tile before my first byte
+    uint32_t f_total;    // emitted bytes of the whole tile
+};
+
+__device__ __forceinline__ void tile_analyse(const uint8_t *__restrict__ raw, uint64_t len, uint64_t tile,
+                                             const BzxSplitWs &ws, uint64_t *scratch64, uint32_t *scratch32, TileInfo &ti)
+{
+    tile_load(raw, len, tile, ti.t);
+    uint64_t tot;
+    const uint64_t rs_prev = block_excl_max64(lane_last_rs(ti.t), scratch64, tot);
+    const uint64_t carry = ws.tile_rs[tile];
+    const uint64_t rs_in = rs_prev ? rs_prev : carry;
+    const uint32_t cnt = lane_emission(ti.t, rs_in, ti.e_bits, ti.k_first);
+    ti.f_excl = bzx_block_excl_sum<RL_NT>(cnt, scratch32, ti.f_total);
+}
+
+// ---- B: emitted bytes per tile
+__global__ __launch_bounds__(RL_NT) void bzx_rl_count_kernel(const uint8_t *__restrict__ raw, uint64_t len,
+                                                             uint64_t ntiles, BzxSplitWs ws)
+{
+    __shared__ uint64_t s64[RL_NT / 64];
+    __shared__ uint32_t s32[RL_NT / 64];
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        TileInfo ti;
+        tile_analyse(raw, len, tile, ws, s64, s32, ti);
+        if (threadIdx.x == 0) ws.tile_off[tile] = ti.f_total;
+        __syncthreads();
+    }
+}
+
+// end of the piece that contains position x (x < len): first piece start after x
+__device__ uint64_t piece_end(const uint8_t *__restrict__ raw, uint64_t len, uint64_t x, uint32_t k_at_x)
+{
+    const uint8_t c = raw[x];
+    uint64_t q = x + 1;
+    uint32_t k = k_at_x + 1;
+    while (q < len && k < 255 && raw[q] == c) {
+        q++;
+        k++;
+    }
+    return q;
+}
+
+// ---- C: block boundaries (single workgroup, serial over blocks)
+__global__ __launch_bounds__(RL_NT) void bzx_rl_boundaries_kernel(const uint8_t *__restrict__ raw, uint64_t len,
+                                                                  uint64_t ntiles, uint32_t nmax, BzxSplitWs ws)
+{
+    __shared__ uint64_t s64[RL_NT / 64];
+    __shared__ uint32_t s32[RL_NT / 64];
+    __shared__ uint64_t s_x;      // candidate position
+    __shared__ uint32_t s_k;      // k at the candidate
+    __shared__ uint64_t s_next, s_fnext;
+    const uint32_t tid = threadIdx.x;
+    uint64_t start = 0, f_start = 0;
+    uint32_t nb = 0;
+    const uint64_t f_len = ws.tile_off[ntiles];
+    while (start < len && nb < ws.max_blocks) {
+        if (tid == 0) {
+            ws.blk_raw[nb] = start;
+            ws.blk_f[nb] = f_start;
+        }
+        nb++;
+        const uint64_t target = f_start + nmax;
+        if (f_len < target) {
+            start = len;
+            f_start = f_len;
+            break;
+        }
+        // largest tile with F(tile start) < target   (tile_off is non-decreasing; tile_off[0] = 0 < target)
+        uint64_t lo = 0, hi = ntiles;   // invariant: tile_off[lo] < target; hi = first tile with tile_off >= target or ntiles
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (ws.tile_off[mid] < target) lo = mid; else hi = mid;
+        }
+        const uint64_t tile = lo;
+        TileInfo ti;
+        tile_analyse(raw, len, tile, ws, s64, s32, ti);
+        // smallest x with F(x) >= target inside this tile, or the start of the next tile
+        if (tid == 0) {
+            s_x = (tile + 1) * RL_TILE < len ? (tile + 1) * RL_TILE : len;
+            s_k = 0xffffffffu;
+        }
+        __syncthreads();
+        {
+            const uint64_t f0 = ws.tile_off[tile] + ti.f_excl;
+            uint64_t f = f0;
+            uint32_t k = ti.k_first;
+            uint32_t prev = ti.t.prev;
+            bool found = false;
+            uint64_t fx = 0;
+            uint32_t kx = 0;
+            for (int i = 0; i < RL_BYTES; i++) {
+                if ((uint32_t)i < ti.t.nvalid) {
+                    const uint32_t c = tile_byte(ti.t, i);
+                    if (i > 0) k = (c != prev) ? 0u : (k + 1 == 255 ? 0u : k + 1);
+                    if (!found && f >= target) {
+                        found = true;
+                        fx = ti.t.p0 + i;
+                        kx = k;
+                    }
+                    f += (ti.e_bits >> (2 * i)) & 3u;
+                    prev = c;
+                }
+            }
+            // lanes are ordered by position: the first lane that found one owns the minimum
+            const uint64_t any = __ballot(found);
+            if (any && (int)bzx_lane() == __ffsll((unsigned long long)any) - 1) {
+                // lowest wave wins: atomicMin on position
+                atomicMin((unsigned long long *)&s_x, (unsigned long long)fx);
+            }
+            __syncthreads();
+            if (found && fx == s_x) s_k = kx;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            uint64_t x = s_x, q;
+            if (x >= len) {
+                q = len;
+            } else if (s_k == 0xffffffffu) {
+                // x is the first byte of the next tile: its k is not known here; derive it from its run start
+                uint64_t rs1 = ws.tile_rs[tile + 1];        // run start (+1) carried into that tile
+                const bool newrun = raw[x] != raw[x - 1];
+                uint32_t k = newrun ? 0u : (uint32_t)((x - (rs1 ? rs1 - 1 : 0)) % 255u);
+                q = (k == 0) ? x : piece_end(raw, len, x, k);
+            } else {
+                q = (s_k == 0) ? x : piece_end(raw, len, x, s_k);
+            }
+            s_next = q;
+        }
+        __syncthreads();
+        const uint64_t q = s_next;
+        // F(q): emitted bytes before q
+        if (q >= len) {
+            if (tid == 0) s_fnext = f_len;
+        } else {
+            const uint64_t qt = q / RL_TILE;
+            TileInfo tq;
+            tile_analyse(raw, len, qt, ws, s64, s32, tq);
+            uint64_t f = ws.tile_off[qt] + tq.f_excl;
+            for (int i = 0; i < RL_BYTES; i++) {
+                if (tq.t.p0 + i == q) s_fnext = f;
+                f += (tq.e_bits >> (2 * i)) & 3u;
+            }
+        }
+        __syncthreads();
+        start = q;
+        f_start = s_fnext;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        ws.blk_raw[nb] = len;
+        ws.blk_f[nb] = f_len;
+        ws.nblk[0] = (start < len) ? 0xffffffffu : nb;   // more blocks than max_blocks: error marker
+    }
+}
+
+// ---- D: scatter the emitted bytes into the block slabs + fill the block descriptors' in_off / n
+__global__ __launch_bounds__(RL_NT) void bzx_rl_scatter_kernel(const uint8_t *__restrict__ raw, uint64_t len,
+                                                               uint64_t ntiles, BzxSplitWs ws, uint8_t *__restrict__ slabs,
+                                                               BzxBlock *__restrict__ blk)
+{
+    __shared__ uint64_t s64[RL_NT / 64];
+    __shared__ uint32_t s32[RL_NT / 64];
+    const uint32_t nblk = ws.nblk[0];
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        TileInfo ti;
+        tile_analyse(raw, len, tile, ws, s64, s32, ti);
+        if (ti.t.nvalid) {
+            // block of my first byte: last block with blk_raw <= p0
+            uint32_t lo = 0, hi = nblk;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ws.blk_raw[mid] <= ti.t.p0) lo = mid; else hi = mid;
+            }
+            uint32_t kb = lo;
+            uint64_t next_raw = ws.blk_raw[kb + 1];
+            uint64_t f0 = ws.blk_f[kb];
+            uint8_t *dst = slabs + (size_t)kb * BZX_BLK_STRIDE;
+            uint64_t f = ws.tile_off[tile] + ti.f_excl;
+            for (int i = 0; i < RL_BYTES; i++) {
+                if ((uint32_t)i < ti.t.nvalid) {
+                    const uint64_t p = ti.t.p0 + i;
+                    if (p >= next_raw) {
+                        kb++;
+                        next_raw = ws.blk_raw[kb + 1];
+                        f0 = ws.blk_f[kb];
+                        dst = slabs + (size_t)kb * BZX_BLK_STRIDE;
+                    }
+                    const uint32_t e = (uint32_t)(ti.e_bits >> (2 * i)) & 3u;
+                    if (e) {
+                        const uint32_t c = tile_byte(ti.t, i);
+                        dst[f - f0] = (uint8_t)c;
+                        if (e == 2) {
+                            // 4th byte of a piece: count the rest of the piece (<= 251 more equal bytes)
+                            uint64_t q = p + 1;
+                            uint32_t extra = 0;
+                            while (q < len && extra < 251 && raw[q] == c) {
+                                q++;
+                                extra++;
+                            }
+                            dst[f - f0 + 1] = (uint8_t)extra;
+                        }
+                        f += e;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t b = blockIdx.x * RL_NT + threadIdx.x; b < nblk; b += gridDim.x * RL_NT) {
+        blk[b].in_off = (uint64_t)b * BZX_BLK_STRIDE;
+        blk[b].n = (uint32_t)(ws.blk_f[b + 1] - ws.blk_f[b]);
+        blk[b].status = 0;
+    }
+}
+
+// ---- E: CRC-32/BZIP2 of every block's raw range
+__device__ __forceinline__ uint32_t gf_mulmod(uint32_t a, uint32_t b)
+{
+    // a(x) * b(x) mod P(x), P = x^32 + 0x04C11DB7, bit 31 = x^31
+    uint32_t r = 0;
+    for (int i = 31; i >= 0; i--) {
+        r = (r << 1) ^ ((r & 0x80000000u) ? 0x04C11DB7u : 0u);
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return r;
+}
+
+// x^(8*nbytes) mod P
+__device__ uint32_t gf_xpow8(uint64_t nbytes)
+{
+    uint32_t result = 1u;            // the polynomial "1"
+    uint32_t sq = 0x100u;            // x^8
+    while (nbytes) {
+        if (nbytes & 1ull) result = gf_mulmod(result, sq);
+        sq = gf_mulmod(sq, sq);
+        nbytes >>= 1;
+    }
+    return result;
+}
+
+#define CRC_NT 1024
+__global__ __launch_bounds__(CRC_NT) void bzx_rl_crc_kernel(const uint8_t *__restrict__ raw, BzxSplitWs ws,
+                                                            BzxBlock *__restrict__ blk)
+{
+    __shared__ uint32_t tab[256];
+    __shared__ uint32_t part[CRC_NT];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 256) {
+        uint32_t c = tid << 24;
+        for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : (c << 1);
+        tab[tid] = c;
+    }
+    __syncthreads();
+    const uint32_t nblk = ws.nblk[0];
+    for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const uint64_t lo = ws.blk_raw[b], hi = ws.blk_raw[b + 1];
+        const uint64_t total = hi - lo;
+        const uint64_t per = (total + CRC_NT - 1) / CRC_NT;
+        const uint64_t a = lo + (uint64_t)tid * per < hi ? lo + (uint64_t)tid * per : hi;
+        const uint64_t e = a + per < hi ? a + per : hi;
+        uint32_t r = 0;
+        for (uint64_t p = a; p < e; p++) r = (r << 8) ^ tab[(r >> 24) ^ raw[p]];
+        part[tid] = r;
+        __syncthreads();
+        // chunk i has length len_i; state = state * x^(8 len_i) + r_i, folded as a tree with equal-length halves
+        // except for the tail: do the simple serial fold by one wave-free lane over 1024 entries (cheap).
+        if (tid == 0) {
+            uint32_t s = 0xffffffffu;
+            const uint32_t xp = gf_xpow8(per);
+            for (uint32_t i = 0; i < CRC_NT; i++) {
+                const uint64_t ai = lo + (uint64_t)i * per;
+                if (ai >= hi) break;
+                const uint64_t li = ai + per < hi ? per : hi - ai;
+                s = gf_mulmod(s, li == per ? xp : gf_xpow8(li)) ^ part[i];
+            }
+            blk[b].crc = ~s;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- host orchestration
+struct bzx_ctx;
+int bzx_ctx_split_scratch(bzx_ctx *ctx, size_t bytes, void **p);   // bzx_api.hip
+hipStream_t bzx_ctx_stream(bzx_ctx *ctx);
+int bzx_ctx_ncu(bzx_ctx *ctx);
+
+// Launches A..C; writes the block count to ws.nblk (device).  max_blocks bounds the descriptor arrays.
+int bzx_split_launch_boundaries(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t max_blocks,
+                                BzxSplitWs *ws_out)
+{
+    const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE;
+    const size_t bytes = (2 * (ntiles + 2) + 2 * ((size_t)max_blocks + 2)) * sizeof(uint64_t) + 64;
+    void *p = nullptr;
+    int rc = bzx_ctx_split_scratch(ctx, bytes, &p);
+    if (rc) return rc;
+    BzxSplitWs ws;
+    ws.tile_rs = (uint64_t *)p;
+    ws.tile_off = ws.tile_rs + (ntiles + 2);
+    ws.blk_raw = ws.tile_off + (ntiles + 2);
+    ws.blk_f = ws.blk_raw + (max_blocks + 2);
+    ws.nblk = (uint32_t *)(ws.blk_f + (max_blocks + 2));
+    ws.max_blocks = max_blocks;
+    hipStream_t st = bzx_ctx_stream(ctx);
+    const uint32_t grid = (uint32_t)(ntiles < (uint64_t)bzx_ctx_ncu(ctx) * 8 ? ntiles : (uint64_t)bzx_ctx_ncu(ctx) * 8);
+    const uint32_t nmax = 100000u * (uint32_t)level - 19u;
+    hipLaunchKernelGGL(bzx_rl_runstart_kernel, dim3(grid), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, ws);
+    hipLaunchKernelGGL(bzx_rl_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_rs, ntiles, 1);
+    hipLaunchKernelGGL(bzx_rl_count_kernel, dim3(grid), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, ws);
+    hipLaunchKernelGGL(bzx_rl_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_off, ntiles, 0);
+    hipLaunchKernelGGL(bzx_rl_boundaries_kernel, dim3(1), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, nmax, ws);
+    *ws_out = ws;
+    return 0;
+}
+
+// Launches D and E for nblk blocks (ws.nblk on the device already holds nblk).
+void bzx_split_launch_scatter(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, const BzxSplitWs &ws, uint32_t nblk,
+                              uint8_t *d_slabs, BzxBlock *d_blk)
+{
+    const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE;
+    hipStream_t st = bzx_ctx_stream(ctx);
+    const uint32_t grid = (uint32_t)(ntiles < (uint64_t)bzx_ctx_ncu(ctx) * 8 ? ntiles : (uint64_t)bzx_ctx_ncu(ctx) * 8);
+    hipLaunchKernelGGL(bzx_rl_scatter_kernel, dim3(grid), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, ws, d_slabs, d_blk);
+    const uint32_t cgrid = nblk < (uint32_t)bzx_ctx_ncu(ctx) * 2 ? nblk : (uint32_t)bzx_ctx_ncu(ctx) * 2;
+    hipLaunchKernelGGL(bzx_rl_crc_kernel, dim3(cgrid), dim3(CRC_NT), 0, st, d_raw, ws, d_blk);
+}
+
+uint32_t *bzx_split_nblk_ptr(const BzxSplitWs &ws) { return ws.nblk; }

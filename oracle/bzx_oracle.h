@@ -49,7 +49,8 @@ uint32_t bzo_stream_crc(uint32_t combined, uint32_t block_crc);
 /*
  * RLE1 + block split with libbz2 semantics (replaces rle1.rs:89-223).
  * Consumes raw[*pos..len) until the block is full (nblock >= 100000*level-19 tested before
- * each input byte) or the input ends (pending run flushed into this block).
+ * each input byte) or the input ends (pending run flushed into this block unless it is full:
+ * BZ_RUN-mode feeding as done by the bzip2 CLI and python's bz2).
  * Writes the RLE1 bytes to blk (capacity >= 100000*level), returns nblock; *crc gets the CRC
  * of the raw bytes this block covers; *pos is advanced past the consumed raw bytes.
  * The pending run (state_ch,state_len) is carried between calls in st[2]; initialise st to

@@ -95,8 +95,11 @@ size_t bzo_rle1_block(const uint8_t *raw, size_t len, size_t *pos, int level, ui
             st[1]++;
         }
     }
-    if (p >= len && st[0] < 256) {
-        /* end of input: flush the pending run into this block */
+    if (p >= len && nblock < nmax && st[0] < 256) {
+        /* end of input: flush the pending run into this block -- unless the block is already full:
+         * the bzip2 CLI and python's bz2 feed libbz2 in BZ_RUN mode, where a full block is cut the
+         * moment nblock >= nblockMAX is seen, before the compressor learns that the input has ended;
+         * the pending run then forms a last block of its own. */
         nblock = rle1_flush_run(st, blk, nblock, &crc);
         st[0] = 256;
         st[1] = 0;

@@ -51,6 +51,13 @@ class BzxLib:
         L.bzx_compress_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
         L.bzx_get_stats.argtypes = [C.c_void_p, C.POINTER(BzxStats)]
+        L.bzx_compress_buffer.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t,
+                                          C.POINTER(C.c_size_t)]
+        L.bzx_compress_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                          C.POINTER(C.c_size_t)]
+        L.bzx_split_rle1.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.bzx_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         self.ctx = C.c_void_p()
         self._check(L.bzx_ctx_create(device, max_blocks, C.byref(self.ctx)))
 
@@ -116,6 +123,29 @@ class BzxLib:
     def compress_block(self, blk: bytes, crc: int):
         return self.compress_blocks([blk], [crc])[0]
 
+    def compress_buffer(self, data: bytes, level=9):
+        cap = len(data) + len(data) // 50 + 4096
+        out = C.create_string_buffer(cap)
+        ol = C.c_size_t()
+        self._check(self.lib.bzx_compress_buffer(self.ctx, data, len(data), level, out, cap, C.byref(ol)))
+        return out.raw[:ol.value]
+
+    def compress_device(self, d_raw_ptr, nbytes, level, d_out_ptr, cap):
+        """Device pointers in, stream length out (nothing but the length crosses PCIe)."""
+        ol = C.c_size_t()
+        self._check(self.lib.bzx_compress_device(self.ctx, d_raw_ptr, nbytes, level, d_out_ptr, cap, C.byref(ol)))
+        return ol.value
+
+    def split_rle1(self, data: bytes, level=9):
+        nmax = 100000 * level - 19
+        cap = (len(data) + len(data) // 4) // nmax + 2
+        slabs = C.create_string_buffer(cap * 900000)
+        ns = (C.c_uint32 * cap)()
+        crcs = (C.c_uint32 * cap)()
+        nb = C.c_uint32()
+        self._check(self.lib.bzx_split_rle1(self.ctx, data, len(data), level, slabs, cap, ns, crcs, C.byref(nb)))
+        return [(slabs.raw[b * 900000:b * 900000 + ns[b]], crcs[b]) for b in range(nb.value)]
+
     def stats(self):
         st = BzxStats()
         self._check(self.lib.bzx_get_stats(self.ctx, C.byref(st)))
@@ -156,6 +186,22 @@ class Oracle:
         lens = [list(T.len[t][:alpha]) for t in range(T.n_groups)]
         codes = [list(T.code[t][:alpha]) for t in range(T.n_groups)]
         return T.n_groups, list(T.selector[:T.n_selectors]), lens, codes
+
+    def split_rle1(self, data: bytes, level=9):
+        self.lib.bzo_rle1_block.restype = C.c_size_t
+        self.lib.bzo_rle1_block.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, C.c_void_p,
+                                            C.c_char_p, C.POINTER(C.c_uint32)]
+        st = (C.c_uint32 * 2)(256, 0)
+        pos = C.c_size_t(0)
+        blk = C.create_string_buffer(100000 * level + 16)
+        out = []
+        while pos.value < len(data) or st[0] < 256:
+            crc = C.c_uint32()
+            n = self.lib.bzo_rle1_block(data, len(data), C.byref(pos), level, st, blk, C.byref(crc))
+            if n == 0:
+                break
+            out.append((blk.raw[:n], crc.value))
+        return out
 
     def crc32(self, data: bytes):
         self.lib.bzo_crc32.restype = C.c_uint32

@@ -1,0 +1,126 @@
+"""-m gpu: parity of every device stage, of the per-block C ABI and of the whole-stream C ABI
+against the oracle (oracle/), libbz2 (python bz2) and the golden fixtures.  Bit-exact: this is
+integer/byte work, there is no tolerance."""
+import bz2
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "streams.json")))
+
+
+def _cases(oracle):
+    rnd = random.Random(11)
+    yield "one", b"a"
+    yield "two_equal", b"aa"                       # periodic
+    yield "banana", b"banana"
+    yield "silly", b"Making a silly test."         # reference KAT string (symbol_map.rs:45-59)
+    yield "text20k", oracle.synthtext(20000)
+    yield "lowent", bytes(rnd.choice(b"ab") for _ in range(60000))
+    yield "bytes256", rnd.randbytes(100000)
+    yield "zeros_rle", b"\0\0\0\0\xfb" * 2000 + b"\0\0\0\0\x10"    # RLE1 image of zeros, not periodic
+    yield "text900k", oracle.synthtext(899981)
+    yield "rand900k", oracle.randbytes(899981)
+    yield "maxblock", oracle.synthtext(900000)     # largest block the ABI accepts
+    yield "mix", b"\0" * 300000 + oracle.synthtext(300000) + b"\xff" * 299000
+
+
+def test_stage_bwt(bzx, oracle):
+    """bwt_encode contract (bwt_sort.rs:27-58): last column and origPtr."""
+    for name, blk in _cases(oracle):
+        L, orig, status = bzx.stage_bwt(blk)
+        Lo, oo = oracle.bwt(blk)
+        assert L == Lo, name
+        assert orig == oo, name
+
+
+def test_stage_mtf(bzx, oracle):
+    """rle2_mtf_encode contract (rle2_mtf.rs:23-177): symbols, histogram, bytes in use."""
+    for name, blk in _cases(oracle):
+        L, _ = oracle.bwt(blk)
+        mt, fr, iu = bzx.stage_mtf(L)
+        mo, fo, iuo, _ = oracle.mtf(L)
+        assert mt == mo, name
+        assert fr == fo, name
+        assert iu == iuo, name
+
+
+def test_stage_huffman(bzx, oracle):
+    """huf_encode table optimisation (huffman.rs:87-374): tables, selectors, lengths, codes."""
+    for name, blk in _cases(oracle):
+        L, _ = oracle.bwt(blk)
+        mo, fo, _, niu = oracle.mtf(L)
+        got = bzx.stage_huffman(mo, fo, niu + 2)
+        want = oracle.huff(mo, fo, niu + 2)
+        assert got == want, name
+
+
+def test_compress_block(bzx, oracle):
+    """compress_block (compress_block.rs:24-67): byte-aligned image + pad bits."""
+    for name, blk in _cases(oracle):
+        crc = oracle.crc32(blk)
+        assert bzx.compress_block(blk, crc) == oracle.compress_block(blk, crc), name
+
+
+def test_compress_blocks_batched(bzx, oracle):
+    """Batched form (compress.rs:125-132): many ragged blocks at once, more blocks than CUs*slots is fine."""
+    rnd = random.Random(5)
+    blocks = [oracle.synthtext(rnd.randint(1, 30000), seed=1000 + i) for i in range(40)]
+    blocks += [rnd.randbytes(rnd.randint(1, 5000)) for _ in range(20)]
+    crcs = [oracle.crc32(b) for b in blocks]
+    got = bzx.compress_blocks(blocks, crcs)
+    for i, b in enumerate(blocks):
+        assert got[i] == oracle.compress_block(b, crcs[i]), i
+
+
+def test_split_rle1(bzx, oracle):
+    """RLE1Block (rle1.rs:33-263) with libbz2's split rule + do_crc (crc.rs:15-22)."""
+    rnd = random.Random(3)
+
+    def runs(n, maxrun, alphabet):
+        out = bytearray()
+        while len(out) < n:
+            out += bytes([rnd.choice(alphabet)]) * rnd.randint(1, maxrun)
+        return bytes(out[:n])
+
+    cases = [(oracle.synthtext(250000), 1), (runs(300000, 600, b"ab\0"), 1), (b"\0" * 6_000_000, 1),
+             (runs(250000, 7, b"abc"), 1), (b"aaaaab", 9), (b"x" * 255 + b"y" * 256 + b"z" * 4, 9),
+             (oracle.synthtext(99982), 1), (b"ab" * 49989 + b"c" * 259, 1), (oracle.synthtext(2_000_000), 9),
+             (runs(3_000_000, 300, bytes(range(256))), 9)]
+    for data, level in cases:
+        assert bzx.split_rle1(data, level) == oracle.split_rle1(data, level)
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN["streams"].keys()))
+def test_stream_golden(bzx, oracle, name):
+    """Whole buffer -> .bz2 (compress.rs:40-136) against the committed libbz2 fixtures and live libbz2."""
+    from gen_golden import make_input
+    g = GOLDEN["streams"][name]
+    data = make_input(oracle, g["input"])
+    out = bzx.compress_buffer(data, g["level"])
+    assert len(out) == g["bz2_len"]
+    assert hashlib.sha256(out).hexdigest() == g["bz2_sha256"]
+    assert out == bz2.compress(data, g["level"])
+
+
+def test_stream_matches_oracle_and_roundtrips(bzx, oracle):
+    """configs[1] + ragged sizes: device stream == oracle stream == libbz2, and libbz2 decodes it."""
+    for n, level in ((899981, 9), (1 << 20, 1), (3_000_001, 9), (5, 9), (0, 9)):
+        data = oracle.synthtext(n) if n else b""
+        out = bzx.compress_buffer(data, level)
+        assert out == oracle.compress(data, level)[0]
+        assert bz2.decompress(out) == data
+
+
+def test_bad_arguments(bzx):
+    from bzx_ctypes import BzxError
+    with pytest.raises(BzxError):
+        bzx.stage_bwt(b"")
+    with pytest.raises(BzxError):
+        bzx.compress_buffer(b"abc", 0)
+    with pytest.raises(BzxError):
+        bzx.compress_block(b"x" * 900001, 0)
