@@ -15,6 +15,7 @@
 #include "bzx_device.h"
 
 void bzx_launch_bwt(const BzxBatch &B, uint32_t grid, hipStream_t stream);
+void bzx_launch_periodic(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_mtf(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_huffman(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_emit(const BzxBatch &B, uint32_t grid, hipStream_t stream);
@@ -121,6 +122,7 @@ static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk)
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.selector, (size_t)cap * BZX_SEL_STRIDE))) return rc;
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.selector_mtf, (size_t)cap * BZX_SEL_STRIDE))) return rc;
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.gbits, (size_t)cap * BZX_SEL_STRIDE))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &B.plist, (size_t)cap))) return rc;
     if ((rc = dev_alloc(ctx, ctx->slabs, &ctx->d_outbuf, (size_t)cap * (BZX_OUT_STRIDE / 4)))) return rc;
     if (ctx->h_blk) (void)hipHostFree(ctx->h_blk);
     ctx->h_blk = nullptr;
@@ -252,6 +254,7 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         int rc = ensure_slots(ctx, (uint32_t)ctx->n_cu * per_cu);
         if (rc) return rc;
         bzx_launch_bwt(B, grid, ctx->stream);
+        bzx_launch_periodic(B, grid < 16 ? grid : 16, ctx->stream);   // no-op unless blocks were flagged periodic
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     if ((stages & STG_MTF) && nblk) bzx_launch_mtf(B, grid_for(ctx, nblk, 1), ctx->stream);

@@ -295,7 +295,10 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
             L[j] = T[sa ? sa - 1 : n - 1];
             if (sa == 0) B.blk[b].orig_ptr = j;
         }
-        if (tid == 0) B.blk[b].status = (m > 0) ? BZX_ST_PERIODIC : 0u;
+        if (tid == 0) {
+            B.blk[b].status = (m > 0) ? BZX_ST_PERIODIC : 0u;
+            if (m > 0) B.plist[atomicAdd(&B.counters[5], 1u)] = b;   // tie order fixed up by bzx_periodic.hip
+        }
         __syncthreads();
     }
 }

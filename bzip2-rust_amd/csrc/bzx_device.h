@@ -51,7 +51,8 @@ struct BzxSortWs {
 struct BzxBatch {
     BzxBlock *blk;          // [nblk]
     uint32_t nblk;
-    uint32_t *counters;     // [8] atomic work counters, one per stage kernel (zeroed per batch)
+    uint32_t *counters;     // [64] atomic work counters, one per stage kernel (zeroed per batch); [5] = #periodic
+    uint32_t *plist;        // [nblk] indices of the blocks flagged periodic by the BWT kernel
     const uint8_t *in;      // block slab buffer (RLE1'd bytes), block b at blk[b].in_off
     uint8_t *bwt;           // [nblk][BZX_BLK_STRIDE]  last column L
     uint8_t *rank;          // [nblk][BZX_BLK_STRIDE]  MTF rank of every L byte

@@ -1,0 +1,550 @@
+// bzx_periodic.hip -- origPtr of PERIODIC blocks on gfx950.
+//
+// A block u^k (k > 1) has k identical copies of every rotation.  The last column L does not depend
+// on how ties are ordered, but the 24-bit origPtr (row of rotation 0) does, and the metric is
+// bit-exactness with C bzip2 1.0.8, whose tie order falls out of its block sorter's internals
+// (the reference leaves it unspecified: src/bwt_algorithms/bwt_sort.rs:40-42 sort_unstable).
+// bzx_bwt.hip flags such blocks (BZX_ST_PERIODIC).  For them only, this kernel replays the
+// published libbz2 1.0.8 block-sorting algorithm literally -- "main" sort with its work budget of
+// 9*nblock, "fallback" sort (bucket + doubling with LCG-pivot 3-way quicksort) when the budget runs
+// out or nblock < 10000 -- on ONE lane per block, entirely on the device, and takes origPtr from it.
+// Exactly periodic blocks are vanishingly rare outside all-equal-byte inputs (config 5a: 5 blocks),
+// so this path is about exactness, not speed; it is the only serial code in the pipeline.
+#include <hip/hip_runtime.h>
+#include "bzx_device.h"
+#include "bzx_wg.h"
+
+#define N_RADIX 2
+#define N_QSORT 12
+#define N_SHELL 18
+#define N_OVERSHOOT (N_RADIX + N_QSORT + N_SHELL + 2)
+
+/* ------------------------------------------------------------------ fallback sort */
+
+__device__ static void fb_simple_sort(uint32_t *fmap, const uint32_t *eclass, int32_t lo, int32_t hi)
+{
+    int32_t i, j;
+    uint32_t tmp, ec;
+    if (lo == hi) return;
+    if (hi - lo > 3) {
+        for (i = hi - 4; i >= lo; i--) {
+            tmp = fmap[i];
+            ec = eclass[tmp];
+            for (j = i + 4; j <= hi && ec > eclass[fmap[j]]; j += 4) fmap[j - 4] = fmap[j];
+            fmap[j - 4] = tmp;
+        }
+    }
+    for (i = hi - 1; i >= lo; i--) {
+        tmp = fmap[i];
+        ec = eclass[tmp];
+        for (j = i + 1; j <= hi && ec > eclass[fmap[j]]; j++) fmap[j - 1] = fmap[j];
+        fmap[j - 1] = tmp;
+    }
+}
+
+__device__ static inline void swap_u32(uint32_t *a, uint32_t *b)
+{
+    uint32_t t = *a;
+    *a = *b;
+    *b = t;
+}
+
+__device__ static void vswap(uint32_t *p, int32_t a, int32_t b, int32_t n)
+{
+    while (n > 0) {
+        swap_u32(&p[a], &p[b]);
+        a++;
+        b++;
+        n--;
+    }
+}
+
+#define FB_SMALL 10
+#define STACK_SZ 100
+
+__device__ static void fb_qsort3(uint32_t *fmap, const uint32_t *eclass, int32_t lo_st, int32_t hi_st)
+{
+    int32_t un_lo, un_hi, lt_lo, gt_hi, n, m, sp, lo, hi;
+    uint32_t med, r, r3;
+    int32_t stack_lo[STACK_SZ], stack_hi[STACK_SZ];
+
+    r = 0;
+    sp = 0;
+    stack_lo[sp] = lo_st;
+    stack_hi[sp] = hi_st;
+    sp++;
+
+    while (sp > 0) {
+        sp--;
+        lo = stack_lo[sp];
+        hi = stack_hi[sp];
+        if (hi - lo < FB_SMALL) {
+            fb_simple_sort(fmap, eclass, lo, hi);
+            continue;
+        }
+        r = ((r * 7621) + 1) % 32768;
+        r3 = r % 3;
+        if (r3 == 0)
+            med = eclass[fmap[lo]];
+        else if (r3 == 1)
+            med = eclass[fmap[(lo + hi) >> 1]];
+        else
+            med = eclass[fmap[hi]];
+
+        un_lo = lt_lo = lo;
+        un_hi = gt_hi = hi;
+        for (;;) {
+            for (;;) {
+                if (un_lo > un_hi) break;
+                n = (int32_t)eclass[fmap[un_lo]] - (int32_t)med;
+                if (n == 0) {
+                    swap_u32(&fmap[un_lo], &fmap[lt_lo]);
+                    lt_lo++;
+                    un_lo++;
+                    continue;
+                }
+                if (n > 0) break;
+                un_lo++;
+            }
+            for (;;) {
+                if (un_lo > un_hi) break;
+                n = (int32_t)eclass[fmap[un_hi]] - (int32_t)med;
+                if (n == 0) {
+                    swap_u32(&fmap[un_hi], &fmap[gt_hi]);
+                    gt_hi--;
+                    un_hi--;
+                    continue;
+                }
+                if (n < 0) break;
+                un_hi--;
+            }
+            if (un_lo > un_hi) break;
+            swap_u32(&fmap[un_lo], &fmap[un_hi]);
+            un_lo++;
+            un_hi--;
+        }
+        if (gt_hi < lt_lo) continue;
+
+        n = (lt_lo - lo) < (un_lo - lt_lo) ? (lt_lo - lo) : (un_lo - lt_lo);
+        vswap(fmap, lo, un_lo - n, n);
+        m = (hi - gt_hi) < (gt_hi - un_hi) ? (hi - gt_hi) : (gt_hi - un_hi);
+        vswap(fmap, un_lo, hi - m + 1, m);
+
+        n = lo + un_lo - lt_lo - 1;
+        m = hi - (gt_hi - un_hi) + 1;
+
+        if (n - lo > hi - m) {
+            stack_lo[sp] = lo; stack_hi[sp] = n; sp++;
+            stack_lo[sp] = m; stack_hi[sp] = hi; sp++;
+        } else {
+            stack_lo[sp] = m; stack_hi[sp] = hi; sp++;
+            stack_lo[sp] = lo; stack_hi[sp] = n; sp++;
+        }
+    }
+}
+
+#define SET_BH(z) bhtab[(z) >> 5] |= ((uint32_t)1 << ((z) & 31))
+#define CLEAR_BH(z) bhtab[(z) >> 5] &= ~((uint32_t)1 << ((z) & 31))
+#define ISSET_BH(z) (bhtab[(z) >> 5] & ((uint32_t)1 << ((z) & 31)))
+#define WORD_BH(z) bhtab[(z) >> 5]
+#define UNALIGNED_BH(z) ((z) & 0x1f)
+
+/* fmap: out, n entries.  eclass: scratch, n entries.  bhtab: scratch, 2 + n/32 + 2 words... */
+__device__ static void fallback_sort(const uint8_t *block, uint32_t *fmap, uint32_t *eclass, uint32_t *bhtab,
+                          int32_t nblock)
+{
+    int32_t ftab[257];
+    int32_t H, i, j, k, l, r, cc, cc1, n_not_done, n_bhtab;
+
+    for (i = 0; i < 257; i++) ftab[i] = 0;
+    for (i = 0; i < nblock; i++) ftab[block[i]]++;
+    for (i = 1; i < 257; i++) ftab[i] += ftab[i - 1];
+    for (i = 0; i < nblock; i++) {
+        j = block[i];
+        k = ftab[j] - 1;
+        ftab[j] = k;
+        fmap[k] = (uint32_t)i;
+    }
+
+    n_bhtab = 2 + (nblock / 32);
+    for (i = 0; i < n_bhtab; i++) bhtab[i] = 0;
+    for (i = 0; i < 256; i++) SET_BH(ftab[i]);
+
+    for (i = 0; i < 32; i++) {
+        SET_BH(nblock + 2 * i);
+        CLEAR_BH(nblock + 2 * i + 1);
+    }
+
+    H = 1;
+    for (;;) {
+        j = 0;
+        for (i = 0; i < nblock; i++) {
+            if (ISSET_BH(i)) j = i;
+            k = (int32_t)fmap[i] - H;
+            if (k < 0) k += nblock;
+            eclass[k] = (uint32_t)j;
+        }
+
+        n_not_done = 0;
+        r = -1;
+        for (;;) {
+            k = r + 1;
+            while (ISSET_BH(k) && UNALIGNED_BH(k)) k++;
+            if (ISSET_BH(k)) {
+                while (WORD_BH(k) == 0xffffffffu) k += 32;
+                while (ISSET_BH(k)) k++;
+            }
+            l = k - 1;
+            if (l >= nblock) break;
+            while (!ISSET_BH(k) && UNALIGNED_BH(k)) k++;
+            if (!ISSET_BH(k)) {
+                while (WORD_BH(k) == 0x00000000u) k += 32;
+                while (!ISSET_BH(k)) k++;
+            }
+            r = k - 1;
+            if (r >= nblock) break;
+
+            if (r > l) {
+                n_not_done += (r - l + 1);
+                fb_qsort3(fmap, eclass, l, r);
+                cc = -1;
+                for (i = l; i <= r; i++) {
+                    cc1 = (int32_t)eclass[fmap[i]];
+                    if (cc != cc1) {
+                        SET_BH(i);
+                        cc = cc1;
+                    }
+                }
+            }
+        }
+        H *= 2;
+        if (H > nblock || n_not_done == 0) break;
+    }
+}
+
+/* ------------------------------------------------------------------ main sort */
+
+__device__ static inline int main_gtu(uint32_t i1, uint32_t i2, const uint8_t *block, const uint16_t *quadrant,
+                           uint32_t nblock, int32_t *budget)
+{
+    int32_t k;
+    uint8_t c1, c2;
+    uint16_t s1, s2;
+    int t;
+
+    for (t = 0; t < 12; t++) {
+        c1 = block[i1];
+        c2 = block[i2];
+        if (c1 != c2) return c1 > c2;
+        i1++;
+        i2++;
+    }
+    k = (int32_t)nblock + 8;
+    do {
+        for (t = 0; t < 8; t++) {
+            c1 = block[i1];
+            c2 = block[i2];
+            if (c1 != c2) return c1 > c2;
+            s1 = quadrant[i1];
+            s2 = quadrant[i2];
+            if (s1 != s2) return s1 > s2;
+            i1++;
+            i2++;
+        }
+        if (i1 >= nblock) i1 -= nblock;
+        if (i2 >= nblock) i2 -= nblock;
+        k -= 8;
+        (*budget)--;
+    } while (k >= 0);
+    return 0;
+}
+
+__device__ static const int32_t shell_incs[14] = {1, 4, 13, 40, 121, 364, 1093, 3280, 9841, 29524, 88573, 265720, 797161, 2391484};
+
+__device__ static void main_simple_sort(uint32_t *ptr, const uint8_t *block, const uint16_t *quadrant, int32_t nblock,
+                             int32_t lo, int32_t hi, int32_t d, int32_t *budget)
+{
+    int32_t i, j, h, big_n, hp, rep;
+    uint32_t v;
+
+    big_n = hi - lo + 1;
+    if (big_n < 2) return;
+    hp = 0;
+    while (shell_incs[hp] < big_n) hp++;
+    hp--;
+
+    for (; hp >= 0; hp--) {
+        h = shell_incs[hp];
+        i = lo + h;
+        for (;;) {
+            /* three insertions between budget checks */
+            for (rep = 0; rep < 3; rep++) {
+                if (i > hi) break;
+                v = ptr[i];
+                j = i;
+                while (main_gtu(ptr[j - h] + d, v + d, block, quadrant, (uint32_t)nblock, budget)) {
+                    ptr[j] = ptr[j - h];
+                    j = j - h;
+                    if (j <= (lo + h - 1)) break;
+                }
+                ptr[j] = v;
+                i++;
+            }
+            if (rep < 3) break;
+            if (*budget < 0) return;
+        }
+    }
+}
+
+__device__ static inline uint8_t med3(uint8_t a, uint8_t b, uint8_t c)
+{
+    uint8_t t;
+    if (a > b) { t = a; a = b; b = t; }
+    if (b > c) {
+        b = c;
+        if (a > b) b = a;
+    }
+    return b;
+}
+
+#define MAIN_SMALL 20
+#define MAIN_DEPTH (N_RADIX + N_QSORT)
+
+__device__ static void main_qsort3(uint32_t *ptr, const uint8_t *block, const uint16_t *quadrant, int32_t nblock,
+                        int32_t lo_st, int32_t hi_st, int32_t d_st, int32_t *budget)
+{
+    int32_t un_lo, un_hi, lt_lo, gt_hi, n, m, med, sp, lo, hi, d;
+    int32_t stack_lo[STACK_SZ], stack_hi[STACK_SZ], stack_d[STACK_SZ];
+    int32_t next_lo[3], next_hi[3], next_d[3], tz;
+
+    sp = 0;
+    stack_lo[sp] = lo_st; stack_hi[sp] = hi_st; stack_d[sp] = d_st; sp++;
+
+    while (sp > 0) {
+        sp--;
+        lo = stack_lo[sp]; hi = stack_hi[sp]; d = stack_d[sp];
+        if (hi - lo < MAIN_SMALL || d > MAIN_DEPTH) {
+            main_simple_sort(ptr, block, quadrant, nblock, lo, hi, d, budget);
+            if (*budget < 0) return;
+            continue;
+        }
+        med = (int32_t)med3(block[ptr[lo] + d], block[ptr[hi] + d], block[ptr[(lo + hi) >> 1] + d]);
+
+        un_lo = lt_lo = lo;
+        un_hi = gt_hi = hi;
+        for (;;) {
+            for (;;) {
+                if (un_lo > un_hi) break;
+                n = ((int32_t)block[ptr[un_lo] + d]) - med;
+                if (n == 0) {
+                    swap_u32(&ptr[un_lo], &ptr[lt_lo]);
+                    lt_lo++;
+                    un_lo++;
+                    continue;
+                }
+                if (n > 0) break;
+                un_lo++;
+            }
+            for (;;) {
+                if (un_lo > un_hi) break;
+                n = ((int32_t)block[ptr[un_hi] + d]) - med;
+                if (n == 0) {
+                    swap_u32(&ptr[un_hi], &ptr[gt_hi]);
+                    gt_hi--;
+                    un_hi--;
+                    continue;
+                }
+                if (n < 0) break;
+                un_hi--;
+            }
+            if (un_lo > un_hi) break;
+            swap_u32(&ptr[un_lo], &ptr[un_hi]);
+            un_lo++;
+            un_hi--;
+        }
+        if (gt_hi < lt_lo) {
+            stack_lo[sp] = lo; stack_hi[sp] = hi; stack_d[sp] = d + 1; sp++;
+            continue;
+        }
+        n = (lt_lo - lo) < (un_lo - lt_lo) ? (lt_lo - lo) : (un_lo - lt_lo);
+        vswap(ptr, lo, un_lo - n, n);
+        m = (hi - gt_hi) < (gt_hi - un_hi) ? (hi - gt_hi) : (gt_hi - un_hi);
+        vswap(ptr, un_lo, hi - m + 1, m);
+
+        n = lo + un_lo - lt_lo - 1;
+        m = hi - (gt_hi - un_hi) + 1;
+
+        next_lo[0] = lo;    next_hi[0] = n;     next_d[0] = d;
+        next_lo[1] = m;     next_hi[1] = hi;    next_d[1] = d;
+        next_lo[2] = n + 1; next_hi[2] = m - 1; next_d[2] = d + 1;
+
+#define NSIZE(a) (next_hi[a] - next_lo[a])
+#define NSWAP(a, b) { tz = next_lo[a]; next_lo[a] = next_lo[b]; next_lo[b] = tz; \
+                      tz = next_hi[a]; next_hi[a] = next_hi[b]; next_hi[b] = tz; \
+                      tz = next_d[a];  next_d[a] = next_d[b];   next_d[b] = tz; }
+        if (NSIZE(0) < NSIZE(1)) NSWAP(0, 1);
+        if (NSIZE(1) < NSIZE(2)) NSWAP(1, 2);
+        if (NSIZE(0) < NSIZE(1)) NSWAP(0, 1);
+#undef NSIZE
+#undef NSWAP
+        stack_lo[sp] = next_lo[0]; stack_hi[sp] = next_hi[0]; stack_d[sp] = next_d[0]; sp++;
+        stack_lo[sp] = next_lo[1]; stack_hi[sp] = next_hi[1]; stack_d[sp] = next_d[1]; sp++;
+        stack_lo[sp] = next_lo[2]; stack_hi[sp] = next_hi[2]; stack_d[sp] = next_d[2]; sp++;
+    }
+}
+
+#define SETMASK (1u << 21)
+#define CLEARMASK (~SETMASK)
+#define BIGFREQ(b) (ftab[((b) + 1) << 8] - ftab[(b) << 8])
+
+/* block must have N_OVERSHOOT writable bytes after nblock; quadrant nblock+N_OVERSHOOT entries; ftab 65537. */
+__device__ static void main_sort(uint32_t *ptr, uint8_t *block, uint16_t *quadrant, uint32_t *ftab, int32_t nblock,
+                      int32_t *budget)
+{
+    int32_t i, j, k, ss, sb;
+    int32_t running_order[256], copy_start[256], copy_end[256];
+    uint8_t big_done[256];
+    uint8_t c1;
+    uint16_t s;
+
+    for (i = 65536; i >= 0; i--) ftab[i] = 0;
+
+    j = block[0] << 8;
+    for (i = nblock - 1; i >= 0; i--) {
+        quadrant[i] = 0;
+        j = (j >> 8) | (((uint16_t)block[i]) << 8);
+        ftab[j]++;
+    }
+    for (i = 0; i < N_OVERSHOOT; i++) {
+        block[nblock + i] = block[i];
+        quadrant[nblock + i] = 0;
+    }
+    for (i = 1; i <= 65536; i++) ftab[i] += ftab[i - 1];
+
+    s = (uint16_t)(block[0] << 8);
+    for (i = nblock - 1; i >= 0; i--) {
+        s = (uint16_t)((s >> 8) | (block[i] << 8));
+        j = (int32_t)ftab[s] - 1;
+        ftab[s] = (uint32_t)j;
+        ptr[j] = (uint32_t)i;
+    }
+
+    for (i = 0; i <= 255; i++) {
+        big_done[i] = 0;
+        running_order[i] = i;
+    }
+    {
+        int32_t vv, h = 1;
+        do h = 3 * h + 1; while (h <= 256);
+        do {
+            h = h / 3;
+            for (i = h; i <= 255; i++) {
+                vv = running_order[i];
+                j = i;
+                while (BIGFREQ(running_order[j - h]) > BIGFREQ(vv)) {
+                    running_order[j] = running_order[j - h];
+                    j = j - h;
+                    if (j <= (h - 1)) break;
+                }
+                running_order[j] = vv;
+            }
+        } while (h != 1);
+    }
+
+    for (i = 0; i <= 255; i++) {
+        ss = running_order[i];
+
+        for (j = 0; j <= 255; j++) {
+            if (j != ss) {
+                sb = (ss << 8) + j;
+                if (!(ftab[sb] & SETMASK)) {
+                    int32_t lo = (int32_t)(ftab[sb] & CLEARMASK);
+                    int32_t hi = (int32_t)(ftab[sb + 1] & CLEARMASK) - 1;
+                    if (hi > lo) {
+                        main_qsort3(ptr, block, quadrant, nblock, lo, hi, N_RADIX, budget);
+                        if (*budget < 0) return;
+                    }
+                }
+                ftab[sb] |= SETMASK;
+            }
+        }
+
+        for (j = 0; j <= 255; j++) {
+            copy_start[j] = (int32_t)(ftab[(j << 8) + ss] & CLEARMASK);
+            copy_end[j] = (int32_t)(ftab[(j << 8) + ss + 1] & CLEARMASK) - 1;
+        }
+        for (j = (int32_t)(ftab[ss << 8] & CLEARMASK); j < copy_start[ss]; j++) {
+            k = (int32_t)ptr[j] - 1;
+            if (k < 0) k += nblock;
+            c1 = block[k];
+            if (!big_done[c1]) ptr[copy_start[c1]++] = (uint32_t)k;
+        }
+        for (j = (int32_t)(ftab[(ss + 1) << 8] & CLEARMASK) - 1; j > copy_end[ss]; j--) {
+            k = (int32_t)ptr[j] - 1;
+            if (k < 0) k += nblock;
+            c1 = block[k];
+            if (!big_done[c1]) ptr[copy_end[c1]--] = (uint32_t)k;
+        }
+
+        for (j = 0; j <= 255; j++) ftab[(j << 8) + ss] |= SETMASK;
+
+        big_done[ss] = 1;
+
+        if (i < 255) {
+            int32_t bb_start = (int32_t)(ftab[ss << 8] & CLEARMASK);
+            int32_t bb_size = (int32_t)(ftab[(ss + 1) << 8] & CLEARMASK) - bb_start;
+            int32_t shifts = 0;
+            while ((bb_size >> shifts) > 65534) shifts++;
+            for (j = bb_size - 1; j >= 0; j--) {
+                int32_t a2update = (int32_t)ptr[bb_start + j];
+                uint16_t qval = (uint16_t)(j >> shifts);
+                quadrant[a2update] = qval;
+                if (a2update < N_OVERSHOOT) quadrant[a2update + nblock] = qval;
+            }
+        }
+    }
+}
+
+
+// Workspace layout inside a sort slot (BzxSortWs): ptr = sa[], eclass = isa[], block copy + quadrant in u0,
+// ftab / bhtab in u1.
+__global__ __launch_bounds__(64) void bzx_periodic_kernel(BzxBatch B)
+{
+    const BzxSortWs ws = B.sort_ws[blockIdx.x];
+    const uint32_t n_per = B.counters[5];
+    for (uint32_t li = blockIdx.x; li < n_per; li += gridDim.x) {
+        const uint32_t b = B.plist[li];
+        if (threadIdx.x == 0) {
+            const int32_t n = (int32_t)B.blk[b].n;
+            const uint8_t *T = B.in + B.blk[b].in_off;
+            uint32_t *ptr = ws.sa;
+            uint32_t *eclass = ws.isa;
+            uint8_t *block = (uint8_t *)ws.u0;                                  // n + N_OVERSHOOT bytes
+            uint16_t *quadrant = (uint16_t *)(block + ((n + N_OVERSHOOT + 15) & ~15));   // n + N_OVERSHOOT entries
+            uint32_t *ftab = (uint32_t *)ws.u1;                                 // 65537 words
+            uint32_t *bhtab = ftab + 65600;                                     // n/32 + 8 words
+            bool need_fallback = true;
+            if (n >= 10000) {
+                for (int32_t i = 0; i < n; i++) block[i] = T[i];
+                int32_t budget = n * ((30 - 1) / 3);
+                main_sort(ptr, block, quadrant, ftab, n, &budget);
+                need_fallback = budget < 0;
+            }
+            if (need_fallback) {
+                for (int32_t i = 0; i < n / 32 + 8; i++) bhtab[i] = 0;
+                fallback_sort(T, ptr, eclass, bhtab, n);
+            }
+            for (int32_t i = 0; i < n; i++)
+                if (ptr[i] == 0) {
+                    B.blk[b].orig_ptr = (uint32_t)i;
+                    break;
+                }
+        }
+        __syncthreads();
+    }
+}
+
+void bzx_launch_periodic(const BzxBatch &B, uint32_t grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_periodic_kernel, dim3(grid), dim3(64), 0, stream, B);
+}

@@ -128,6 +128,10 @@ int bzx_stream_append_block(bzx_stream *s, const uint8_t *data, size_t len, uint
 int bzx_stream_finish(bzx_stream *s, const uint8_t **data, size_t *len);
 void bzx_stream_free(bzx_stream *s);
 
+/* Deterministic synthetic inputs (include/bzx_synth.h), host buffers. seed 0 = default. */
+void bzx_synth_text(uint64_t seed, uint8_t *out, size_t nbytes);
+void bzx_synth_random(uint64_t seed, uint8_t *out, size_t nbytes);
+
 #ifdef __cplusplus
 }
 #endif

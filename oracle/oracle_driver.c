@@ -95,63 +95,7 @@ size_t bzo_compress_buffer_mt(const uint8_t *raw, size_t len, int level, int nth
 }
 
 /* ------------------------------------------------------------------ synthetic inputs */
+#include "../include/bzx_synth.h"
 
-static inline uint64_t xs64(uint64_t *s)
-{
-    uint64_t x = *s;
-    x ^= x >> 12;
-    x ^= x << 25;
-    x ^= x >> 27;
-    *s = x;
-    return x * 0x2545F4914F6CDD1Dull;
-}
-
-/*
- * synthtext: vocabulary of 8192 words, word length 2 + r%9, letters a..z uniform with
- * rejection of a 3rd equal consecutive letter; text = words picked with index
- * ((r1 % 8192) * (r2 % 8192)) >> 13 (skewed to low indices), separated by ' ', every 13th
- * separator '\n'.  No byte run of length >= 4 ever occurs, so RLE1 is the identity on it.
- */
-void bzo_synthtext(uint64_t seed, uint8_t *out, size_t nbytes)
-{
-    enum { NW = 8192, MAXL = 10 };
-    static __thread uint8_t vocab[NW][MAXL];
-    static __thread uint8_t vlen[NW];
-    uint64_t s = seed ? seed : 0x9E3779B97F4A7C15ull;
-
-    for (int w = 0; w < NW; w++) {
-        int L = 2 + (int)(xs64(&s) % 9);
-        vlen[w] = (uint8_t)L;
-        for (int k = 0; k < L; k++) {
-            uint8_t c;
-            do {
-                c = (uint8_t)('a' + xs64(&s) % 26);
-            } while (k >= 2 && vocab[w][k - 1] == c && vocab[w][k - 2] == c);
-            vocab[w][k] = c;
-        }
-    }
-    size_t p = 0;
-    uint64_t nword = 0;
-    while (p < nbytes) {
-        uint64_t r1 = xs64(&s), r2 = xs64(&s);
-        uint32_t w = (uint32_t)(((r1 % NW) * (r2 % NW)) >> 13);
-        for (int k = 0; k < vlen[w] && p < nbytes; k++) out[p++] = vocab[w][k];
-        nword++;
-        if (p < nbytes) out[p++] = (nword % 13 == 0) ? '\n' : ' ';
-    }
-}
-
-void bzo_xorshift_bytes(uint64_t seed, uint8_t *out, size_t nbytes)
-{
-    uint64_t s = seed ? seed : 0xD1B54A32D192ED03ull;
-    size_t p = 0;
-    while (p + 8 <= nbytes) {
-        uint64_t r = xs64(&s);
-        memcpy(out + p, &r, 8);
-        p += 8;
-    }
-    if (p < nbytes) {
-        uint64_t r = xs64(&s);
-        memcpy(out + p, &r, nbytes - p);
-    }
-}
+void bzo_synthtext(uint64_t seed, uint8_t *out, size_t nbytes) { bzx_synth_text_impl(seed, out, nbytes); }
+void bzo_xorshift_bytes(uint64_t seed, uint8_t *out, size_t nbytes) { bzx_synth_random_impl(seed, out, nbytes); }
