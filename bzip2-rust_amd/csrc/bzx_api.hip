@@ -28,6 +28,8 @@ int bzx_split_launch_boundaries(struct bzx_ctx *ctx, const uint8_t *d_raw, size_
 void bzx_split_launch_scatter(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, const BzxSplitWs &ws,
                               uint32_t nblk, uint8_t *d_slabs, BzxBlock *d_blk);
 uint32_t bzx_bwt_max_blocks_per_cu();
+void bzx_launch_bits_export(const BzxBatch &B, long long *bits, hipStream_t stream);
+void bzx_launch_bits_import(const BzxBatch &B, const long long *bits, hipStream_t stream);
 
 struct bzx_ctx {
     int device = 0;
@@ -49,6 +51,11 @@ struct bzx_ctx {
     uint64_t *h_scalars = nullptr;   // pinned
     hipEvent_t ev[8];
     bzx_stats stats;
+
+    // sharded run state (bzx_shard_prepare -> bzx_shard_emit)
+    uint32_t shard_total = 0, shard_rank = 0, shard_world = 1;
+    int shard_level = 0;
+    size_t shard_len = 0;
 
     // device split scratch (bzx_rle1.hip)
     void *split_ws = nullptr;
@@ -246,6 +253,7 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
     BzxBatch &B = ctx->B;
     B.nblk = nblk;
     B.counters = ctx->d_counters;
+    if (B.blk_step == 0) B.blk_step = 1;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 64 * sizeof(uint32_t), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if ((stages & STG_BWT) && nblk) {
@@ -640,4 +648,96 @@ extern "C" int bzx_split_rle1(bzx_ctx *ctx, const uint8_t *raw, size_t len, int 
     (void)hipFree(d_raw);
     if (!rc) *nblk_out = nblk;
     return rc;
+}
+
+// ---- multi-GPU sharding: block i belongs to rank i mod world; no collective in here.
+// The caller all-reduces (sum) d_bits between the two calls and sums the partial streams afterwards
+// (torch.distributed / RCCL; see bench.py).  Declared in include/bzx.h.
+extern "C" int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, int level, uint32_t rank, uint32_t world,
+                                 uint32_t *nblk_total, long long *d_bits, size_t bits_cap)
+{
+    if (!ctx || !nblk_total || !d_bits || !level_ok(level) || world == 0 || rank >= world || (len && !d_raw)) return BZX_E_PARAM;
+    if ((uintptr_t)d_raw & 15u) return BZX_E_PARAM;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    uint32_t nblk = 0;
+    ctx->B.blk_first = 0;
+    ctx->B.blk_step = 1;
+    int rc = split_on_device(ctx, (const uint8_t *)d_raw, len, level, &nblk);
+    if (rc) return rc;
+    if (nblk > bits_cap) return BZX_E_OUTBUF;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    const uint32_t mine = nblk > rank ? (nblk - rank + world - 1) / world : 0;
+    ctx->B.blk_first = rank;
+    ctx->B.blk_step = world;
+    rc = run_stages(ctx, mine, STG_BWT | STG_MTF | STG_HUF);
+    if (!rc && mine) bzx_launch_bits_export(ctx->B, d_bits, ctx->stream);
+    ctx->B.blk_first = 0;
+    ctx->B.blk_step = 1;
+    if (rc) return rc;
+    ctx->shard_total = nblk;
+    ctx->shard_rank = rank;
+    ctx->shard_world = world;
+    ctx->shard_level = level;
+    ctx->shard_len = len;
+    *nblk_total = nblk;
+    return BZX_OK;
+}
+
+extern "C" int bzx_shard_emit(bzx_ctx *ctx, const long long *d_bits_all, void *d_out, size_t cap, size_t *out_len)
+{
+    if (!ctx || !d_bits_all || !d_out || !out_len || ((uintptr_t)d_out & 3u)) return BZX_E_PARAM;
+    if (ctx->shard_level == 0) return BZX_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BzxBatch &B = ctx->B;
+    const uint32_t nblk = ctx->shard_total, rank = ctx->shard_rank, world = ctx->shard_world;
+    B.nblk = nblk;
+    B.blk_first = 0;
+    B.blk_step = 1;
+    B.out = (uint32_t *)d_out;
+    if (nblk) bzx_launch_bits_import(B, d_bits_all, ctx->stream);
+    bzx_launch_layout(B, 32, 0, ctx->d_scalars, ctx->stream);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t out_bytes = (ctx->h_scalars[0] + 80 + 7) >> 3;
+    const uint64_t need = (out_bytes + 3) & ~3ull;
+    if (need > (cap & ~(size_t)3)) {
+        ctx->err = "output buffer too small for the compressed stream";
+        return BZX_E_OUTBUF;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(d_out, 0, need, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 64 * sizeof(uint32_t), ctx->stream));
+    if (rank == 0) bzx_launch_stream_frame(B, ctx->shard_level, ctx->d_scalars, ctx->d_scalars + 1, ctx->stream);
+    const uint32_t mine = nblk > rank ? (nblk - rank + world - 1) / world : 0;
+    B.nblk = mine;
+    B.blk_first = rank;
+    B.blk_step = world;
+    if (mine) bzx_launch_emit(B, grid_for(ctx, mine, 2), ctx->stream);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    if (nblk) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_blk, B.blk, nblk * sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    B.nblk = nblk;
+    B.blk_first = 0;
+    B.blk_step = 1;
+    *out_len = (size_t)out_bytes;
+    // stats over my blocks
+    bzx_stats &st = ctx->stats;
+    collect_stage_times(ctx);
+    st.nblk = mine;
+    st.n_periodic = 0;
+    st.raw_bytes = ctx->shard_len / world;
+    st.rle1_bytes = 0;
+    st.mtf_symbols = 0;
+    for (uint32_t b = rank; b < nblk; b += world) {
+        const BzxBlock &d = ctx->h_blk[b];
+        st.n_periodic += (d.status & BZX_ST_PERIODIC) ? 1 : 0;
+        st.rle1_bytes += d.n;
+        st.mtf_symbols += d.n_mtf;
+    }
+    st.out_bits = out_bytes * 8;
+    (void)hipEventElapsedTime(&st.ms_split, ctx->ev[5], ctx->ev[6]);
+    (void)hipEventElapsedTime(&st.ms_total, ctx->ev[5], ctx->ev[7]);
+    return BZX_OK;
 }

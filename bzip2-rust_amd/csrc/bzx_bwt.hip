@@ -231,9 +231,10 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
     for (;;) {
         if (tid == 0) s_bcast[0] = atomicAdd(&B.counters[0], 1u);
         __syncthreads();
-        const uint32_t b = s_bcast[0];
+        const uint32_t j_ = s_bcast[0];
         __syncthreads();
-        if (b >= B.nblk) break;
+        if (j_ >= B.nblk) break;
+        const uint32_t b = B.blk_first + j_ * B.blk_step;
 
         const uint32_t n = B.blk[b].n;
         const uint8_t *__restrict__ T = B.in + B.blk[b].in_off;

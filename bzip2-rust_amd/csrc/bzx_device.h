@@ -50,7 +50,9 @@ struct BzxSortWs {
 // Everything a stage kernel needs for a batch of blocks.
 struct BzxBatch {
     BzxBlock *blk;          // [nblk]
-    uint32_t nblk;
+    uint32_t nblk;          // blocks this launch works on: logical j in [0,nblk) -> block blk_first + j*blk_step
+    uint32_t blk_first;     // round-robin sharding over GPUs: first = rank, step = world size
+    uint32_t blk_step;
     uint32_t *counters;     // [64] atomic work counters, one per stage kernel (zeroed per batch); [5] = #periodic
     uint32_t *plist;        // [nblk] indices of the blocks flagged periodic by the BWT kernel
     const uint8_t *in;      // block slab buffer (RLE1'd bytes), block b at blk[b].in_off

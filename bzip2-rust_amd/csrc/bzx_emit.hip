@@ -79,9 +79,10 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
     for (;;) {
         if (tid == 0) e_bcast[0] = atomicAdd(&B.counters[3], 1u);
         __syncthreads();
-        const uint32_t b = e_bcast[0];
+        const uint32_t j_ = e_bcast[0];
         __syncthreads();
-        if (b >= B.nblk) break;
+        if (j_ >= B.nblk) break;
+        const uint32_t b = B.blk_first + j_ * B.blk_step;
 
         const BzxBlock d = B.blk[b];
         const uint32_t alpha = d.n_in_use + 2, n_mtf = d.n_mtf, n_sel = d.n_selectors, n_groups = d.n_groups;
@@ -277,6 +278,28 @@ __global__ void bzx_stream_frame_kernel(BzxBatch B, int level, const uint64_t *t
     w.put(32, combined);
     w.finish();
     out_bytes[0] = (end + 80 + 7) >> 3;
+}
+
+// Sharded runs (round-robin blocks over GPUs): export my blocks' sizes / import everybody's sizes.
+__global__ void bzx_bits_export_kernel(BzxBatch B, long long *bits)
+{
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < B.nblk; j += gridDim.x * blockDim.x) {
+        const uint32_t b = B.blk_first + j * B.blk_step;
+        bits[b] = (long long)B.blk[b].bits;
+    }
+}
+__global__ void bzx_bits_import_kernel(BzxBatch B, const long long *bits)
+{
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B.nblk; b += gridDim.x * blockDim.x)
+        B.blk[b].bits = (uint64_t)bits[b];
+}
+void bzx_launch_bits_export(const BzxBatch &B, long long *bits, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_bits_export_kernel, dim3(64), dim3(256), 0, stream, B, bits);
+}
+void bzx_launch_bits_import(const BzxBatch &B, const long long *bits, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_bits_import_kernel, dim3(64), dim3(256), 0, stream, B, bits);
 }
 
 void bzx_launch_emit(const BzxBatch &B, uint32_t grid, hipStream_t stream)

@@ -119,9 +119,10 @@ __global__ __launch_bounds__(HUF_NT) void bzx_huff_kernel(BzxBatch B)
     for (;;) {
         if (tid == 0) h_bcast[0] = atomicAdd(&B.counters[2], 1u);
         __syncthreads();
-        const uint32_t b = h_bcast[0];
+        const uint32_t j_ = h_bcast[0];
         __syncthreads();
-        if (b >= B.nblk) break;
+        if (j_ >= B.nblk) break;
+        const uint32_t b = B.blk_first + j_ * B.blk_step;
 
         const uint32_t n_mtf = B.blk[b].n_mtf;
         const uint32_t alpha = B.blk[b].n_in_use + 2;

@@ -53,9 +53,10 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
     for (;;) {
         if (tid == 0) m_bcast[0] = atomicAdd(&B.counters[1], 1u);
         __syncthreads();
-        const uint32_t b = m_bcast[0];
+        const uint32_t j_ = m_bcast[0];
         __syncthreads();
-        if (b >= B.nblk) break;
+        if (j_ >= B.nblk) break;
+        const uint32_t b = B.blk_first + j_ * B.blk_step;
 
         const uint32_t n = B.blk[b].n;
         const uint8_t *__restrict__ L = B.bwt + (size_t)b * BZX_BLK_STRIDE;

@@ -104,6 +104,22 @@ int bzx_compress_device(bzx_ctx *ctx, const void *d_raw, size_t len, int level, 
 int bzx_compress_buffer(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level, uint8_t *out, size_t cap,
                         size_t *out_len);
 
+/*
+ * Multi-GPU sharding (replaces the rayon fan-out over blocks, compress.rs:125-132, across
+ * devices): bzip2 block i belongs to rank i mod world.  No collective happens inside the library; the
+ * caller (one process per GPU) exchanges 8 bytes per block between the two calls:
+ *   1. bzx_shard_prepare: split the whole input (block boundaries are a serial dependency over the
+ *      stream, so every rank derives them from its copy of the raw bytes), run BWT/MTF/Huffman on this
+ *      rank's blocks, write their sizes in bits to d_bits[i] (int64, device; other entries untouched).
+ *   2. caller: all-reduce(sum) d_bits over the ranks.
+ *   3. bzx_shard_emit: lay out the whole stream from all sizes and emit this rank's blocks at their final
+ *      bit positions into d_out (zero elsewhere; rank 0 also writes "BZh<level>" and the footer).
+ *   4. caller: reduce(sum) of d_out[0..out_len) to rank 0 == the finished .bz2 (bit ranges are disjoint).
+ */
+int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, int level, uint32_t rank, uint32_t world,
+                      uint32_t *nblk_total, long long *d_bits, size_t bits_cap);
+int bzx_shard_emit(bzx_ctx *ctx, const long long *d_bits_all, void *d_out, size_t cap, size_t *out_len);
+
 /* Per-call telemetry of the last bzx_compress_device/_buffer/_blocks call. */
 typedef struct {
     uint32_t nblk;
