@@ -47,6 +47,7 @@ struct bzx_ctx {
     uint32_t *d_outbuf = nullptr;   // per-block output slabs (per-block entry points)
     uint32_t *d_counters = nullptr;
     uint64_t *d_scalars = nullptr;   // [0] total bits, [1] out bytes
+    unsigned long long *d_dbg = nullptr;   // [64] phase timers, only when bzx_dbg_phase_timers(ctx, 1)
     BzxBlock *h_blk = nullptr;       // pinned mirror
     uint64_t *h_scalars = nullptr;   // pinned
     hipEvent_t ev[8];
@@ -739,5 +740,21 @@ extern "C" int bzx_shard_emit(bzx_ctx *ctx, const long long *d_bits_all, void *d
     st.out_bits = out_bytes * 8;
     (void)hipEventElapsedTime(&st.ms_split, ctx->ev[5], ctx->ev[6]);
     (void)hipEventElapsedTime(&st.ms_total, ctx->ev[5], ctx->ev[7]);
+    return BZX_OK;
+}
+
+// Debug helper (not in include/bzx.h): enable/read the BWT kernel's phase timers (100 MHz wall-clock ticks summed over blocks).
+extern "C" int bzx_dbg_phase_timers(bzx_ctx *ctx, int enable, unsigned long long out[64])
+{
+    if (!ctx) return BZX_E_PARAM;
+    if (enable && !ctx->d_dbg) {
+        if (hipMalloc((void **)&ctx->d_dbg, 64 * sizeof(unsigned long long)) != hipSuccess) return BZX_E_NOMEM;
+    }
+    if (out && ctx->d_dbg) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(out, ctx->d_dbg, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    if (ctx->d_dbg) HIP_TRY(ctx, hipMemset(ctx->d_dbg, 0, 64 * sizeof(unsigned long long)));
+    ctx->B.dbg = enable ? ctx->d_dbg : nullptr;
     return BZX_OK;
 }

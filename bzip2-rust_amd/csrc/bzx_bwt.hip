@@ -129,8 +129,10 @@ __device__ uint32_t rerank(const uint64_t *__restrict__ U, const uint32_t *__res
     if (tid == 0) {
         s_bcast[1] = 0;
         s_bcast[2] = 0;
+        s_bcast[3] = 0;
     }
     __syncthreads();
+    uint32_t my_maxgrp = 0;
     for (uint32_t t0 = 0; t0 < m; t0 += SORT_NT * SORT_E) {
         const uint32_t k0 = t0 + tid * SORT_E;
         const uint32_t carry_ks = s_bcast[1], carry_cnt = s_bcast[2];
@@ -165,6 +167,7 @@ __device__ uint32_t rerank(const uint64_t *__restrict__ U, const uint32_t *__res
             if (k < m) {
                 if (f[j]) ks = k + 1;
                 const uint32_t kstart = ks - 1;
+                if (k - kstart + 1 > my_maxgrp) my_maxgrp = k - kstart + 1;
                 const uint32_t newrank = INITIAL ? kstart : S[kstart];
                 const uint32_t sa = (uint32_t)(r[j + 1] & SA_MASK);
                 const uint32_t pos = INITIAL ? k : S[k];
@@ -183,6 +186,8 @@ __device__ uint32_t rerank(const uint64_t *__restrict__ U, const uint32_t *__res
         }
         __syncthreads();
     }
+    atomicMax(&s_bcast[3], my_maxgrp);
+    __syncthreads();
     const uint32_t res = s_bcast[2];
     __syncthreads();
     return res;
@@ -223,8 +228,151 @@ __device__ void gather_keys(uint64_t *__restrict__ U, uint32_t m, const uint32_t
     __syncthreads();
 }
 
+// ---- fast refinement round: every group fits one wave tile --------------------------------------
+// When the largest group has <= SEG_T members, a doubling round needs no global radix passes: each
+// wave walks its share of the compacted records in tiles of SEG_T (8 per lane) cut at group
+// boundaries, gathers key2 = ISA[(sa+h) mod n], sorts the tile by (g, key2) with a register/cross-lane
+// bitonic network and writes it back in place.  No LDS, no workgroup barriers; HBM traffic is one
+// 8-byte read + one 8-byte write per record plus the 4-byte gather.
+#define SEG_T 512
+#define SEG_PER_LANE 8
+
+__device__ __forceinline__ void cmpx(uint64_t &a, uint64_t &b, bool asc)
+{
+    const bool sw = (a > b) == asc;
+    const uint64_t t = a;
+    a = sw ? b : a;
+    b = sw ? t : b;
+}
+
+__device__ __forceinline__ void bitonic512(uint64_t (&v)[SEG_PER_LANE], uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t k = 2; k <= SEG_T; k <<= 1) {
+#pragma unroll
+        for (uint32_t st = k >> 1; st > 0; st >>= 1) {
+            if (st >= SEG_PER_LANE) {
+                const uint32_t lst = st / SEG_PER_LANE;          // lane stride
+                const bool lower = (lane & lst) == 0;
+#pragma unroll
+                for (int j = 0; j < SEG_PER_LANE; j++) {
+                    const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
+                    const bool asc = (e & k) == 0;
+                    const uint64_t o = __shfl_xor(v[j], (int)lst);
+                    const bool keep_min = lower == asc;
+                    v[j] = keep_min ? (v[j] < o ? v[j] : o) : (v[j] > o ? v[j] : o);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < SEG_PER_LANE; j++) {
+                    const int pj = j ^ (int)st;
+                    if (pj > j) {
+                        const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
+                        cmpx(v[j], v[pj], (e & k) == 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// first group start at or after r0 (groups have <= SEG_T members), or m
+__device__ __forceinline__ uint32_t seg_align(const uint64_t *__restrict__ U, uint32_t m, uint32_t r0, uint32_t lane)
+{
+    if (r0 == 0) return 0;
+    if (r0 >= m) return m;
+    uint32_t best = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < SEG_PER_LANE; j++) {
+        const uint32_t i = r0 + lane * SEG_PER_LANE + (uint32_t)j;
+        if (i < m) {
+            if ((U[i] >> 40) != (U[i - 1] >> 40) && i < best) best = i;
+        } else if (m < best) {
+            best = m;
+        }
+    }
+    // wave minimum
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t o = __shfl_xor(best, d);
+        best = o < best ? o : best;
+    }
+    return best;
+}
+
+__device__ void seg_sort_round(uint64_t *__restrict__ U, uint32_t m, const uint32_t *__restrict__ ISA, uint32_t n,
+                               uint32_t h)
+{
+    const uint32_t lane = bzx_lane(), wave = bzx_wave();
+    const uint32_t share = (m + SORT_NW - 1) / SORT_NW;
+    uint32_t a = seg_align(U, m, wave * share < m ? wave * share : m, lane);
+    const uint32_t end = seg_align(U, m, (wave + 1) * share < m ? (wave + 1) * share : m, lane);
+    while (a < end) {
+        const uint32_t lim = (end - a < SEG_T) ? end : a + SEG_T;     // tile may reach at most lim
+        uint64_t v[SEG_PER_LANE];
+#pragma unroll
+        for (int j = 0; j < SEG_PER_LANE; j++) {
+            const uint32_t i = a + lane * SEG_PER_LANE + (uint32_t)j;
+            v[j] = i < lim ? U[i] : ~0ull;
+        }
+        // b = last group boundary in (a, lim]  (lim == end is a boundary)
+        uint32_t b = lim;
+        if (lim != end) {
+            const uint64_t nxt0 = __shfl_down(v[0], 1);     // first record of the next lane
+            uint64_t after = nxt0;
+            if (lane == 63) after = U[lim];                 // lim < end <= m
+            uint32_t best = 0;
+#pragma unroll
+            for (int j = 0; j < SEG_PER_LANE; j++) {
+                const uint32_t i = a + lane * SEG_PER_LANE + (uint32_t)j + 1;       // candidate boundary index
+                const uint64_t cur = v[j];
+                const uint64_t nx = (j + 1 < SEG_PER_LANE) ? v[(j + 1) & (SEG_PER_LANE - 1)] : after;
+                if (i <= lim && (nx >> 40) != (cur >> 40)) best = i;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                const uint32_t o = __shfl_xor(best, d);
+                best = o > best ? o : best;
+            }
+            b = best;       // > a because the group starting at a has <= SEG_T members
+            if (b <= a) b = lim;   // defensive: never stall (cannot happen when the size bound holds)
+        }
+        // gather key2 for the records of this tile, mask the rest
+#pragma unroll
+        for (int j = 0; j < SEG_PER_LANE; j++) {
+            const uint32_t i = a + lane * SEG_PER_LANE + (uint32_t)j;
+            if (i < b) {
+                uint32_t p = (uint32_t)(v[j] & SA_MASK) + h;
+                if (p >= n) p -= n;
+                v[j] |= (uint64_t)ISA[p] << 20;
+            } else {
+                v[j] = ~0ull;
+            }
+        }
+        bitonic512(v, lane);
+#pragma unroll
+        for (int j = 0; j < SEG_PER_LANE; j++) {
+            const uint32_t i = a + lane * SEG_PER_LANE + (uint32_t)j;
+            if (i < b) U[i] = v[j];
+        }
+        a = b;
+    }
+    __syncthreads();
+}
+
+// diagnostic phase timers (B.dbg != null only in profiling runs): accumulate wall-clock ticks per phase
+#define PHASE_STAMP(slot)                                                     \
+    do {                                                                      \
+        if (B.dbg && tid == 0) {                                              \
+            const unsigned long long now_ = wall_clock64();                   \
+            atomicAdd(&B.dbg[slot], now_ - t_last);                           \
+            t_last = now_;                                                    \
+        }                                                                     \
+    } while (0)
+
 __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
 {
+    unsigned long long t_last = 0;
     const uint32_t tid = threadIdx.x;
     const BzxSortWs ws = B.sort_ws[blockIdx.x];
 
@@ -239,6 +387,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         const uint32_t n = B.blk[b].n;
         const uint8_t *__restrict__ T = B.in + B.blk[b].in_off;
         uint8_t *__restrict__ L = B.bwt + (size_t)b * BZX_BLK_STRIDE;
+        if (B.dbg && tid == 0) t_last = wall_clock64();
 
         // ---- I1: records [first 4 bytes | i] and their four digit histograms
         for (uint32_t i = tid; i < 4 * 256; i += SORT_NT) (&s_hist[0][0])[i] = 0;
@@ -262,32 +411,52 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         }
         __syncthreads();
 
+        PHASE_STAMP(0);
         // ---- I2: four LSD passes over the 32-bit key (record bits 20..51)
         radix_pass(ws.u0, ws.u1, n, 20, s_hist[0]);
         radix_pass(ws.u1, ws.u0, n, 28, s_hist[1]);
         radix_pass(ws.u0, ws.u1, n, 36, s_hist[2]);
         radix_pass(ws.u1, ws.u0, n, 44, s_hist[3]);
 
+        PHASE_STAMP(1);
         // ---- R: ranks by the first four bytes
         uint64_t *ua = ws.u1, *ub = ws.u0;      // ua: current compacted records, ub: sort scratch
         uint32_t *sa_cur = ws.s0, *sa_alt = ws.s1;
         uint32_t m = rerank<true>(ws.u0, nullptr, n, ua, sa_cur, ws.isa, ws.sa);
 
+        PHASE_STAMP(2);
         // ---- doubling rounds
         uint32_t h = 4;
+        uint32_t round = 0;
         while (m > 0 && h < n) {
-            gather_keys(ua, m, ws.isa, n, h);
-            // five passes: ua -> ub -> ua -> ub -> ua -> ub
-            radix_pass(ua, ub, m, 20, s_hist[0]);
-            radix_pass(ub, ua, m, 28, s_hist[1]);
-            radix_pass(ua, ub, m, 36, s_hist[2]);
-            radix_pass(ub, ua, m, 44, s_hist[3]);
-            radix_pass(ua, ub, m, 52, s_hist[4]);
-            m = rerank<false>(ub, sa_cur, m, ua, sa_alt, ws.isa, ws.sa);
+            const uint32_t maxgrp = s_bcast[3];
+            __syncthreads();
+            if (maxgrp <= SEG_T) {
+                // fast round: in-place wave-tile sort of ua, then re-rank into ub
+                seg_sort_round(ua, m, ws.isa, n, h);
+                PHASE_STAMP(8 + (round < 7 ? round : 7) * 3);
+                m = rerank<false>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa);
+                PHASE_STAMP(9 + (round < 7 ? round : 7) * 3);
+                uint64_t *tu = ua;
+                ua = ub;
+                ub = tu;
+            } else {
+                gather_keys(ua, m, ws.isa, n, h);
+                // five passes: ua -> ub -> ua -> ub -> ua -> ub
+                radix_pass(ua, ub, m, 20, s_hist[0]);
+                radix_pass(ub, ua, m, 28, s_hist[1]);
+                radix_pass(ua, ub, m, 36, s_hist[2]);
+                radix_pass(ub, ua, m, 44, s_hist[3]);
+                radix_pass(ua, ub, m, 52, s_hist[4]);
+                PHASE_STAMP(10 + (round < 7 ? round : 7) * 3);
+                m = rerank<false>(ub, sa_cur, m, ua, sa_alt, ws.isa, ws.sa);
+                PHASE_STAMP(9 + (round < 7 ? round : 7) * 3);
+            }
             uint32_t *ts = sa_cur;
             sa_cur = sa_alt;
             sa_alt = ts;
             h <<= 1;
+            round++;
         }
 
         // ---- F: last column and orig_ptr
@@ -296,6 +465,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
             L[j] = T[sa ? sa - 1 : n - 1];
             if (sa == 0) B.blk[b].orig_ptr = j;
         }
+        PHASE_STAMP(3);
         if (tid == 0) {
             B.blk[b].status = (m > 0) ? BZX_ST_PERIODIC : 0u;
             if (m > 0) B.plist[atomicAdd(&B.counters[5], 1u)] = b;   // tie order fixed up by bzx_periodic.hip

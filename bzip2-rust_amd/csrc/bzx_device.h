@@ -70,6 +70,7 @@ struct BzxBatch {
     BzxSortWs *sort_ws;     // [n_slots]
     uint8_t *mtf_ws;        // [n_slots][BZX_MTF_WS]   recency lists of the MTF kernel
     uint32_t n_slots;
+    unsigned long long *dbg; // optional [64] phase timers (100 MHz ticks), null in production
 };
 
 #define BZX_MTF_WS (72u * 1024u)

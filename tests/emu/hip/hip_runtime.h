@@ -182,3 +182,4 @@ struct uint4 { unsigned x, y, z, w; };
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r = {x, y, z, w}; return r; }
 struct uint2 { unsigned x, y; };
 inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r = {x, y}; return r; }
+inline unsigned long long wall_clock64() { return 0; }

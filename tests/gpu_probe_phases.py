@@ -1,0 +1,25 @@
+"""Ad-hoc GPU probe: BWT kernel phase breakdown (diagnostic timers) for a batch of identical blocks."""
+import sys, ctypes as C
+sys.path.insert(0, "tests")
+from bzx_ctypes import *
+o = Oracle(); lib = BzxLib()
+L = lib.lib
+L.bzx_dbg_time_stages.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_int, C.POINTER(C.c_float)]
+L.bzx_dbg_phase_timers.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+kind = sys.argv[1] if len(sys.argv) > 1 else "text"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 1194
+blk = o.synthtext(899981) if kind == "text" else o.randbytes(899981)
+ms = (C.c_float * 4)(); t = (C.c_ulonglong * 64)()
+lib._check(L.bzx_dbg_time_stages(lib.ctx, blk, len(blk), reps, 1, ms))
+lib._check(L.bzx_dbg_phase_timers(lib.ctx, 1, None))
+lib._check(L.bzx_dbg_time_stages(lib.ctx, blk, len(blk), reps, 1, ms))
+lib._check(L.bzx_dbg_phase_timers(lib.ctx, 0, t))
+names = {0: "I1 build", 1: "I2 4 radix passes", 2: "R0 rerank", 3: "F final gather"}
+for r in range(8):
+    names[8 + 3 * r] = f"round{r} seg sort"; names[9 + 3 * r] = f"round{r} rerank"; names[10 + 3 * r] = f"round{r} gather+5 passes"
+tot = sum(t)
+print(f"bwt kernel {ms[0]:.2f} ms for {reps} blocks; phase ticks summed over blocks (per block ms = ticks/100e3/reps):")
+for i in range(64):
+    if t[i]:
+        print(f"  {names.get(i, i):28s} {t[i] / 100e3 / reps:8.3f} ms/block  {100.0 * t[i] / tot:5.1f}%")
+print(f"  total {tot / 100e3 / reps:.3f} ms/block")

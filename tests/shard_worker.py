@@ -1,0 +1,64 @@
+"""Worker of tests/test_shard_gloo.py: one rank of the round-robin block sharding over gloo.
+Runs the REAL C ABI (bzx_shard_prepare / bzx_shard_emit) through the CPU kernel emulator (tests/emu), with
+CPU tensors standing in for HBM, so the N>1 control flow is exercised without GPUs."""
+import bz2
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bzx_ctypes import EMU_PATH, BzxLib, Oracle  # noqa: E402
+
+
+def main():
+    rank, world, port, nbytes = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = port
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    level = 1
+    o = Oracle()
+    data = np.frombuffer(o.synthtext(nbytes) , dtype=np.uint8).copy()
+    raw = np.zeros(data.nbytes + 64, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 16
+    raw[off:off + data.nbytes] = data
+    lib = BzxLib(EMU_PATH)
+    L = lib.lib
+    L.bzx_shard_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32,
+                                    C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
+    L.bzx_shard_emit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    bits = torch.zeros(64, dtype=torch.int64)
+    nblk = C.c_uint32()
+    lib._check(L.bzx_shard_prepare(lib.ctx, raw.ctypes.data + off, data.nbytes, level, rank, world, C.byref(nblk),
+                                   bits.data_ptr(), bits.numel()))
+    mine = bits.clone()
+    dist.all_reduce(bits)
+    # every block size is reported by exactly one rank
+    owners = torch.zeros(64, dtype=torch.int64)
+    owners[:nblk.value] = (mine[:nblk.value] > 0).to(torch.int64)
+    dist.all_reduce(owners)
+    assert bool((owners[:nblk.value] == 1).all()), owners
+    assert all(int(mine[b]) > 0 for b in range(rank, nblk.value, world))
+    cap = data.nbytes + 65536
+    out = torch.zeros(cap // 4, dtype=torch.int32)
+    ol = C.c_size_t()
+    lib._check(L.bzx_shard_emit(lib.ctx, bits.data_ptr(), out.data_ptr(), cap, C.byref(ol)))
+    n4 = (ol.value + 3) // 4
+    part = out[:n4].clone()
+    dist.reduce(part, dst=0)          # disjoint bit ranges: sum == OR
+    if rank == 0:
+        z = part.numpy().tobytes()[:ol.value]
+        want = bz2.compress(data.tobytes(), level)
+        assert z == want, (len(z), len(want))
+        assert nblk.value == 3
+        print("SHARD_OK", nblk.value, len(z))
+    dist.barrier()
+    dist.destroy_process_group()
+    lib.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,39 @@
+"""CPU test (-m "not gpu") of the N>1 path: world size 2 over gloo on 127.0.0.1.
+Two processes run bzx_shard_prepare -> all_reduce(block sizes) -> bzx_shard_emit -> reduce(sum) exactly as
+bench.py does with RCCL, but through the kernel emulator (tests/emu) with CPU tensors; rank 0's result must be
+byte-identical to libbz2's stream of the whole input."""
+import os
+import socket
+import subprocess
+import sys
+
+from bzx_ctypes import EMU_PATH, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_round_robin_sharding_world2(oracle):
+    srcs = [os.path.join(ROOT, "bzip2-rust_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "bzip2-rust_amd", "csrc"))]
+    if not os.path.exists(EMU_PATH) or any(os.path.getmtime(s) > os.path.getmtime(EMU_PATH) for s in srcs):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+    port = str(_free_port())
+    worker = os.path.join(ROOT, "tests", "shard_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, "230000"], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=600)
+            outs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "SHARD_OK 3" in outs[0], outs[0]
