@@ -3,25 +3,27 @@
 // Contract (reference src/bwt_algorithms/bwt_sort.rs:27-58, bwt_encode): sort all cyclic
 // rotations of the block, L[j] = byte preceding the j-th smallest rotation, orig_ptr = row
 // of rotation 0.  The reference sorts with a comparator (bwt_sort.rs:61-86) or SA-IS
-// (sais_fallback.rs:469-578); neither maps to a GPU.  Here one workgroup sorts one block by
-// cyclic PREFIX DOUBLING on 64-bit records
-//        [ group start g : 20 | rank of rotation sa+h : 20 | sa : 20 ]
-// with an LSD radix sort (8-bit digits, wave64 match-any ranking, LDS digit offsets) over
-// the still-unresolved rotations only:
-//   I1  build records [first 4 bytes : 32 | i : 20], 4 digit histograms          (n)
-//   I2  4 radix passes                                                            (n each)
-//   R   re-rank: group boundaries, new ranks -> ISA, positions -> SA, compact the
-//       unresolved rotations                                                      (m)
-//   loop h = 4, 8, 16, ... while unresolved and h < n:
-//       G  gather key2 = ISA[(sa+h) mod n], 5 digit histograms                    (m)
-//       5 radix passes over (g, key2)                                             (m each)
-//       R  re-rank + compact                                                      (m)
-//   F   L[j] = T[SA[j]-1], orig_ptr
-// Rotations still tied when h >= n are identical: the block is periodic and
-// is flagged BZX_ST_PERIODIC; L is unaffected by the tie order.
+// (sais_fallback.rs:469-578); neither maps to a GPU.  Here one workgroup (1024 lanes) sorts one
+// block, keeping only the rotations that are still tied ("unresolved") from round to round:
 //
-// HBM-bound integer work: all traffic is 8-byte records streamed coalesced, plus one 4-byte
-// random read (G) and one 4-byte random write (R) per unresolved rotation and round.
+//   I1  records [first 4 bytes:32 | i:20 | preceding byte:8], 4 digit histograms          (n)
+//   I2  4 stable LSD radix passes (8-bit digits, wave64 match-any ranking, LDS offsets)   (n each)
+//   R   re-rank: group boundaries, SA[pos] = sa, L[pos] = preceding byte, compaction of the
+//       rotations in groups of size > 1 to records [group start g:20 | .. | sa:20 | prev:8] (m)
+//   TEXT rounds (depth 4, 12, 20, 28; while every group has <= 512 members):
+//       each wave sorts tiles of <= 512 records, cut at group boundaries, by (g, next 8 text
+//       bytes at sa+depth) with a register / cross-lane bitonic network; the tile-local start of
+//       every new group is stored in the record so R sees the new boundaries.  No ISA exists in
+//       this mode: the only random accesses are 8-byte reads of the 900 KB block itself.     (m)
+//   RANK rounds (only for deep repeats / large groups; h doubles): ISA is built once from SA,
+//       then key2 = ISA[(sa+h) mod n]; tiles as above when groups are small, else five global
+//       LSD passes over [g:20 | key2:20 | sa:20]; R also maintains ISA.                      (m)
+//   F   (RANK mode only) L[j] = T[SA[j]-1], orig_ptr
+// Rotations still tied when depth >= n are identical: the block is periodic and
+// is flagged BZX_ST_PERIODIC (tie order fixed by bzx_periodic.hip); L is unaffected.
+//
+// HBM-bound integer work: records stream coalesced as 8-byte words; see DESIGN.md section 6 for the
+// measured traffic.
 #include <hip/hip_runtime.h>
 #include "bzx_device.h"
 #include "bzx_wg.h"
@@ -30,12 +32,25 @@
 #define SORT_NW (SORT_NT / 64)
 #define SORT_E 4
 #define SA_MASK 0xFFFFFull
+// record layouts (bit positions)
+//   INIT : [key32 @28..59][i @8..27][prev @0..7]
+//   TEXT : [g @44..63][loc @28..37][sa @8..27][prev @0..7]      group key = rec >> 28
+//   RANK : [g @44..63][key2 @24..43][sa @4..23]                  group key = rec >> 24
+#define G_SHIFT 44
+#define TXT_KEY_SHIFT 28
+#define TXT_SA_SHIFT 8
+#define RNK_KEY_SHIFT 24
+#define RNK_SA_SHIFT 4
+#define MODE_INIT 0
+#define MODE_TEXT 1
+#define MODE_RANK 2
+#define TEXT_ROUNDS 4
 
 __shared__ uint32_t s_hist[5][256];
 __shared__ uint32_t s_base[256];
 __shared__ uint32_t s_wcnt[2][SORT_NW * 256];
 __shared__ uint32_t s_scratch[2 * SORT_NW];
-__shared__ uint32_t s_bcast[4];   // [0] block index, [1] carry group start (+1), [2] carry count, [3] orig_ptr
+__shared__ uint32_t s_bcast[4];   // [0] block index, [1] carry group start (+1), [2] carry count, [3] largest group
 
 // Add one to hist[d]; when the whole wave holds the same digit a single lane adds the count.
 __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t d, bool valid)
@@ -116,15 +131,18 @@ __device__ void radix_pass(const uint64_t *__restrict__ src, uint64_t *__restric
     __syncthreads();
 }
 
-// Re-rank the sorted records U[0..m): a new group starts wherever (rec >> 20) changes.
-// new rank = SA position of the group's first member; ISA[sa] = rank; SA[pos] = sa; the members of
-// groups of size > 1 are compacted to Unew/Snew (record = rank << 40 | sa, slot = SA position).
-// Returns the number of unresolved rotations.
-template <bool INITIAL>
+// Re-rank the sorted records U[0..m): a new group starts wherever the group key (rec >> KEY_SHIFT) changes.
+// new rank = SA position of the group's first member; SA[pos] = sa; in INIT/TEXT mode L[pos] = preceding byte,
+// in RANK mode ISA[sa] = rank.  Members of groups of size > 1 are compacted to Unew/Snew (slot = SA position).
+// Returns the number of unresolved rotations; s_bcast[3] = size of the largest group.
+template <int MODE>
 __device__ uint32_t rerank(const uint64_t *__restrict__ U, const uint32_t *__restrict__ S, uint32_t m,
                            uint64_t *__restrict__ Unew, uint32_t *__restrict__ Snew, uint32_t *__restrict__ ISA,
-                           uint32_t *__restrict__ SA)
+                           uint32_t *__restrict__ SA, uint8_t *__restrict__ L, uint32_t *__restrict__ orig_out)
 {
+    constexpr int KEY_SHIFT = (MODE == MODE_RANK) ? RNK_KEY_SHIFT : TXT_KEY_SHIFT;
+    constexpr int SA_SHIFT = (MODE == MODE_RANK) ? RNK_SA_SHIFT : TXT_SA_SHIFT;
+    constexpr bool INITIAL = (MODE == MODE_INIT);
     const uint32_t tid = threadIdx.x;
     if (tid == 0) {
         s_bcast[1] = 0;
@@ -146,7 +164,7 @@ __device__ uint32_t rerank(const uint64_t *__restrict__ U, const uint32_t *__res
 #pragma unroll
         for (int j = 0; j <= SORT_E; j++) {
             const uint32_t k = k0 + j;
-            f[j] = (k >= m) || (k == 0) || ((r[j + 1] >> 20) != (r[j] >> 20));
+            f[j] = (k >= m) || (k == 0) || ((r[j + 1] >> KEY_SHIFT) != (r[j] >> KEY_SHIFT));
         }
         uint32_t my_ks = 0, my_cnt = 0;
 #pragma unroll
@@ -169,12 +187,17 @@ __device__ uint32_t rerank(const uint64_t *__restrict__ U, const uint32_t *__res
                 const uint32_t kstart = ks - 1;
                 if (k - kstart + 1 > my_maxgrp) my_maxgrp = k - kstart + 1;
                 const uint32_t newrank = INITIAL ? kstart : S[kstart];
-                const uint32_t sa = (uint32_t)(r[j + 1] & SA_MASK);
+                const uint64_t rec = r[j + 1];
+                const uint32_t sa = (uint32_t)(rec >> SA_SHIFT) & 0xFFFFFu;
                 const uint32_t pos = INITIAL ? k : S[k];
-                ISA[sa] = newrank;
                 SA[pos] = sa;
+                if (MODE == MODE_RANK) ISA[sa] = newrank;
+                else L[pos] = (uint8_t)rec;
+                if (sa == 0) *orig_out = pos;
                 if (!(f[j] && f[j + 1])) {
-                    Unew[o] = ((uint64_t)newrank << 40) | (uint64_t)sa;
+                    Unew[o] = (MODE == MODE_RANK)
+                                  ? (((uint64_t)newrank << G_SHIFT) | ((uint64_t)sa << RNK_SA_SHIFT))
+                                  : (((uint64_t)newrank << G_SHIFT) | ((uint64_t)sa << TXT_SA_SHIFT) | (rec & 0xFFull));
                     Snew[o] = pos;
                     o++;
                 }
@@ -211,7 +234,7 @@ __device__ void gather_keys(uint64_t *__restrict__ U, uint32_t m, const uint32_t
 #pragma unroll
         for (int e = 0; e < SORT_E; e++) {
             const uint32_t k = t0 + e * SORT_NT + tid;
-            uint32_t p = (uint32_t)(rec[e] & SA_MASK) + h;
+            uint32_t p = ((uint32_t)(rec[e] >> RNK_SA_SHIFT) & 0xFFFFFu) + h;
             if (p >= n) p -= n;
             key2[e] = k < m ? ISA[p] : 0u;
         }
@@ -219,33 +242,37 @@ __device__ void gather_keys(uint64_t *__restrict__ U, uint32_t m, const uint32_t
         for (int e = 0; e < SORT_E; e++) {
             const uint32_t k = t0 + e * SORT_NT + tid;
             const bool valid = k < m;
-            const uint64_t x = rec[e] | ((uint64_t)key2[e] << 20);
+            const uint64_t x = rec[e] | ((uint64_t)key2[e] << RNK_KEY_SHIFT);
             if (valid) U[k] = x;
 #pragma unroll
-            for (int p = 0; p < 5; p++) hist_add(s_hist[p], (uint32_t)(x >> (20 + 8 * p)) & 255u, valid);
+            for (int p = 0; p < 5; p++) hist_add(s_hist[p], (uint32_t)(x >> (RNK_KEY_SHIFT + 8 * p)) & 255u, valid);
         }
     }
     __syncthreads();
 }
 
-// ---- fast refinement round: every group fits one wave tile --------------------------------------
-// When the largest group has <= SEG_T members, a doubling round needs no global radix passes: each
-// wave walks its share of the compacted records in tiles of SEG_T (8 per lane) cut at group
-// boundaries, gathers key2 = ISA[(sa+h) mod n], sorts the tile by (g, key2) with a register/cross-lane
-// bitonic network and writes it back in place.  No LDS, no workgroup barriers; HBM traffic is one
-// 8-byte read + one 8-byte write per record plus the 4-byte gather.
+// ---- tile rounds: every group fits one wave tile ---------------------------------------------------
+// When the largest group has <= SEG_T members a refinement round needs no global radix passes: each
+// wave walks its share of the compacted records in tiles of SEG_T (8 per lane) cut at group boundaries,
+// fetches the secondary key (TEXT: the next 8 block bytes, big-endian; RANK: ISA[(sa+h) mod n]), sorts
+// the tile by (g, key) with a register / cross-lane bitonic network and writes it back in place.
+// No LDS, no workgroup barriers; HBM traffic is one 8-byte read + one 8-byte write per record plus the
+// key fetch.
 #define SEG_T 512
 #define SEG_PER_LANE 8
 
-__device__ __forceinline__ void cmpx(uint64_t &a, uint64_t &b, bool asc)
+struct SegRec {
+    uint64_t rec;   // memory record
+    uint64_t key;   // secondary key (TEXT: 8 text bytes; RANK: unused, key2 lives inside rec)
+};
+
+__device__ __forceinline__ bool seg_less(const SegRec &a, const SegRec &b)
 {
-    const bool sw = (a > b) == asc;
-    const uint64_t t = a;
-    a = sw ? b : a;
-    b = sw ? t : b;
+    const uint64_t ga = a.rec >> G_SHIFT, gb = b.rec >> G_SHIFT;
+    return ga < gb || (ga == gb && (a.key < b.key || (a.key == b.key && a.rec < b.rec)));
 }
 
-__device__ __forceinline__ void bitonic512(uint64_t (&v)[SEG_PER_LANE], uint32_t lane)
+template <bool TEXT> __device__ __forceinline__ void bitonic512(SegRec (&v)[SEG_PER_LANE], uint32_t lane)
 {
 #pragma unroll
     for (uint32_t k = 2; k <= SEG_T; k <<= 1) {
@@ -258,9 +285,12 @@ __device__ __forceinline__ void bitonic512(uint64_t (&v)[SEG_PER_LANE], uint32_t
                 for (int j = 0; j < SEG_PER_LANE; j++) {
                     const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
                     const bool asc = (e & k) == 0;
-                    const uint64_t o = __shfl_xor(v[j], (int)lst);
+                    SegRec o;
+                    o.rec = __shfl_xor(v[j].rec, (int)lst);
+                    o.key = TEXT ? __shfl_xor(v[j].key, (int)lst) : 0ull;
                     const bool keep_min = lower == asc;
-                    v[j] = keep_min ? (v[j] < o ? v[j] : o) : (v[j] > o ? v[j] : o);
+                    const bool mine_less = TEXT ? seg_less(v[j], o) : (v[j].rec < o.rec);
+                    if (mine_less != keep_min) v[j] = o;
                 }
             } else {
 #pragma unroll
@@ -268,7 +298,13 @@ __device__ __forceinline__ void bitonic512(uint64_t (&v)[SEG_PER_LANE], uint32_t
                     const int pj = j ^ (int)st;
                     if (pj > j) {
                         const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
-                        cmpx(v[j], v[pj], (e & k) == 0);
+                        const bool asc = (e & k) == 0;
+                        const bool less = TEXT ? seg_less(v[j], v[pj]) : (v[j].rec < v[pj].rec);
+                        if (less != asc) {
+                            const SegRec t = v[j];
+                            v[j] = v[pj];
+                            v[pj] = t;
+                        }
                     }
                 }
             }
@@ -286,12 +322,11 @@ __device__ __forceinline__ uint32_t seg_align(const uint64_t *__restrict__ U, ui
     for (int j = 0; j < SEG_PER_LANE; j++) {
         const uint32_t i = r0 + lane * SEG_PER_LANE + (uint32_t)j;
         if (i < m) {
-            if ((U[i] >> 40) != (U[i - 1] >> 40) && i < best) best = i;
+            if ((U[i] >> G_SHIFT) != (U[i - 1] >> G_SHIFT) && i < best) best = i;
         } else if (m < best) {
             best = m;
         }
     }
-    // wave minimum
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         const uint32_t o = __shfl_xor(best, d);
@@ -300,34 +335,54 @@ __device__ __forceinline__ uint32_t seg_align(const uint64_t *__restrict__ U, ui
     return best;
 }
 
-__device__ void seg_sort_round(uint64_t *__restrict__ U, uint32_t m, const uint32_t *__restrict__ ISA, uint32_t n,
-                               uint32_t h)
+// 8 block bytes starting at cyclic position p (p < n), big-endian
+__device__ __forceinline__ uint64_t text_key8(const uint8_t *__restrict__ T, uint32_t n, uint32_t p)
+{
+    if (p + 8 <= n) {
+        uint64_t w;
+        __builtin_memcpy(&w, T + p, 8);      // unaligned 8-byte global load
+        return __builtin_bswap64(w);
+    }
+    uint64_t w = 0;
+    for (int j = 0; j < 8; j++) {
+        w = (w << 8) | T[p];
+        p++;
+        if (p >= n) p = 0;
+    }
+    return w;
+}
+
+// TEXT: key = block bytes [sa+h, sa+h+8) ; RANK: key2 = ISA[(sa+h) mod n] merged into the record.
+template <bool TEXT>
+__device__ void seg_sort_round(uint64_t *__restrict__ U, uint32_t m, const uint32_t *__restrict__ ISA,
+                               const uint8_t *__restrict__ T, uint32_t n, uint32_t h)
 {
     const uint32_t lane = bzx_lane(), wave = bzx_wave();
     const uint32_t share = (m + SORT_NW - 1) / SORT_NW;
     uint32_t a = seg_align(U, m, wave * share < m ? wave * share : m, lane);
     const uint32_t end = seg_align(U, m, (wave + 1) * share < m ? (wave + 1) * share : m, lane);
+    const uint32_t hmod = h % n;
     while (a < end) {
         const uint32_t lim = (end - a < SEG_T) ? end : a + SEG_T;     // tile may reach at most lim
-        uint64_t v[SEG_PER_LANE];
+        SegRec v[SEG_PER_LANE];
 #pragma unroll
         for (int j = 0; j < SEG_PER_LANE; j++) {
             const uint32_t i = a + lane * SEG_PER_LANE + (uint32_t)j;
-            v[j] = i < lim ? U[i] : ~0ull;
+            v[j].rec = i < lim ? U[i] : ~0ull;
+            v[j].key = 0;
         }
         // b = last group boundary in (a, lim]  (lim == end is a boundary)
         uint32_t b = lim;
         if (lim != end) {
-            const uint64_t nxt0 = __shfl_down(v[0], 1);     // first record of the next lane
-            uint64_t after = nxt0;
+            uint64_t after = __shfl_down(v[0].rec, 1);      // first record of the next lane
             if (lane == 63) after = U[lim];                 // lim < end <= m
             uint32_t best = 0;
 #pragma unroll
             for (int j = 0; j < SEG_PER_LANE; j++) {
                 const uint32_t i = a + lane * SEG_PER_LANE + (uint32_t)j + 1;       // candidate boundary index
-                const uint64_t cur = v[j];
-                const uint64_t nx = (j + 1 < SEG_PER_LANE) ? v[(j + 1) & (SEG_PER_LANE - 1)] : after;
-                if (i <= lim && (nx >> 40) != (cur >> 40)) best = i;
+                const uint64_t cur = v[j].rec;
+                const uint64_t nx = (j + 1 < SEG_PER_LANE) ? v[(j + 1) & (SEG_PER_LANE - 1)].rec : after;
+                if (i <= lim && (nx >> G_SHIFT) != (cur >> G_SHIFT)) best = i;
             }
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) {
@@ -337,23 +392,58 @@ __device__ void seg_sort_round(uint64_t *__restrict__ U, uint32_t m, const uint3
             b = best;       // > a because the group starting at a has <= SEG_T members
             if (b <= a) b = lim;   // defensive: never stall (cannot happen when the size bound holds)
         }
-        // gather key2 for the records of this tile, mask the rest
+        // secondary keys for the records of this tile, mask the rest
 #pragma unroll
         for (int j = 0; j < SEG_PER_LANE; j++) {
             const uint32_t i = a + lane * SEG_PER_LANE + (uint32_t)j;
             if (i < b) {
-                uint32_t p = (uint32_t)(v[j] & SA_MASK) + h;
-                if (p >= n) p -= n;
-                v[j] |= (uint64_t)ISA[p] << 20;
+                if (TEXT) {
+                    uint32_t p = ((uint32_t)(v[j].rec >> TXT_SA_SHIFT) & 0xFFFFFu) + hmod;
+                    if (p >= n) p -= n;
+                    v[j].key = text_key8(T, n, p);
+                    v[j].rec &= ~(0x3FFull << TXT_KEY_SHIFT);     // clear the tile-local slot of the last round
+                } else {
+                    uint32_t p = ((uint32_t)(v[j].rec >> RNK_SA_SHIFT) & 0xFFFFFu) + hmod;
+                    if (p >= n) p -= n;
+                    v[j].rec |= (uint64_t)ISA[p] << RNK_KEY_SHIFT;
+                }
             } else {
-                v[j] = ~0ull;
+                v[j].rec = ~0ull;
+                v[j].key = ~0ull;
             }
         }
-        bitonic512(v, lane);
+        bitonic512<TEXT>(v, lane);
+        if (TEXT) {
+            // tile-local index of the first member of every new (g, key) group -> record bits 28..37
+            SegRec pl;                                     // last element of the previous lane
+            pl.rec = __shfl_up(v[SEG_PER_LANE - 1].rec, 1);
+            pl.key = __shfl_up(v[SEG_PER_LANE - 1].key, 1);
+            uint32_t last = 0;                             // 1 + index of the last new-group start in my lane
+            uint32_t fl = 0;
+#pragma unroll
+            for (int j = 0; j < SEG_PER_LANE; j++) {
+                const SegRec &p = j ? v[j - 1] : pl;
+                const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
+                const bool nw = (e == 0) || (v[j].rec >> G_SHIFT) != (p.rec >> G_SHIFT) || v[j].key != p.key;
+                if (nw) {
+                    last = e + 1;
+                    fl |= 1u << j;
+                }
+            }
+            const uint32_t incl = bzx_wave_incl_max(last);
+            uint32_t run = __shfl_up(incl, 1);
+            if (lane == 0) run = 0;
+#pragma unroll
+            for (int j = 0; j < SEG_PER_LANE; j++) {
+                const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
+                if ((fl >> j) & 1u) run = e + 1;
+                v[j].rec |= (uint64_t)((run - 1) & 0x3FFu) << TXT_KEY_SHIFT;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < SEG_PER_LANE; j++) {
             const uint32_t i = a + lane * SEG_PER_LANE + (uint32_t)j;
-            if (i < b) U[i] = v[j];
+            if (i < b) U[i] = v[j].rec;
         }
         a = b;
     }
@@ -389,7 +479,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         uint8_t *__restrict__ L = B.bwt + (size_t)b * BZX_BLK_STRIDE;
         if (B.dbg && tid == 0) t_last = wall_clock64();
 
-        // ---- I1: records [first 4 bytes | i] and their four digit histograms
+        // ---- I1: records [first 4 bytes | i | preceding byte] and their four digit histograms
         for (uint32_t i = tid; i < 4 * 256; i += SORT_NT) (&s_hist[0][0])[i] = 0;
         __syncthreads();
         for (uint32_t t0 = 0; t0 < n; t0 += SORT_NT) {
@@ -404,66 +494,84 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
                     p++;
                     if (p >= n) p = 0;
                 }
-                ws.u0[i] = ((uint64_t)key << 20) | (uint64_t)i;
+                const uint32_t prev = T[i ? i - 1 : n - 1];
+                ws.u0[i] = ((uint64_t)key << TXT_KEY_SHIFT) | ((uint64_t)i << TXT_SA_SHIFT) | (uint64_t)prev;
             }
 #pragma unroll
             for (int p = 0; p < 4; p++) hist_add(s_hist[p], (key >> (8 * p)) & 255u, valid);
         }
         __syncthreads();
-
         PHASE_STAMP(0);
-        // ---- I2: four LSD passes over the 32-bit key (record bits 20..51)
-        radix_pass(ws.u0, ws.u1, n, 20, s_hist[0]);
-        radix_pass(ws.u1, ws.u0, n, 28, s_hist[1]);
-        radix_pass(ws.u0, ws.u1, n, 36, s_hist[2]);
-        radix_pass(ws.u1, ws.u0, n, 44, s_hist[3]);
 
+        // ---- I2: four LSD passes over the 32-bit key (record bits 28..59)
+        radix_pass(ws.u0, ws.u1, n, TXT_KEY_SHIFT, s_hist[0]);
+        radix_pass(ws.u1, ws.u0, n, TXT_KEY_SHIFT + 8, s_hist[1]);
+        radix_pass(ws.u0, ws.u1, n, TXT_KEY_SHIFT + 16, s_hist[2]);
+        radix_pass(ws.u1, ws.u0, n, TXT_KEY_SHIFT + 24, s_hist[3]);
         PHASE_STAMP(1);
-        // ---- R: ranks by the first four bytes
-        uint64_t *ua = ws.u1, *ub = ws.u0;      // ua: current compacted records, ub: sort scratch
-        uint32_t *sa_cur = ws.s0, *sa_alt = ws.s1;
-        uint32_t m = rerank<true>(ws.u0, nullptr, n, ua, sa_cur, ws.isa, ws.sa);
 
+        // ---- R: ranks by the first four bytes
+        uint64_t *ua = ws.u1, *ub = ws.u0;      // ua: current compacted records, ub: the other buffer
+        uint32_t *sa_cur = ws.s0, *sa_alt = ws.s1;
+        uint32_t *orig_out = &B.blk[b].orig_ptr;
+        uint32_t m = rerank<MODE_INIT>(ws.u0, nullptr, n, ua, sa_cur, ws.isa, ws.sa, L, orig_out);
         PHASE_STAMP(2);
-        // ---- doubling rounds
-        uint32_t h = 4;
-        uint32_t round = 0;
-        while (m > 0 && h < n) {
-            const uint32_t maxgrp = s_bcast[3];
+
+        // ---- TEXT rounds: 8 more block bytes per round, tiles only
+        uint32_t depth = 4, round = 0;
+        while (m > 0 && depth < n && round < TEXT_ROUNDS && s_bcast[3] <= SEG_T) {
             __syncthreads();
-            if (maxgrp <= SEG_T) {
-                // fast round: in-place wave-tile sort of ua, then re-rank into ub
-                seg_sort_round(ua, m, ws.isa, n, h);
-                PHASE_STAMP(8 + (round < 7 ? round : 7) * 3);
-                m = rerank<false>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa);
-                PHASE_STAMP(9 + (round < 7 ? round : 7) * 3);
-                uint64_t *tu = ua;
-                ua = ub;
-                ub = tu;
-            } else {
-                gather_keys(ua, m, ws.isa, n, h);
-                // five passes: ua -> ub -> ua -> ub -> ua -> ub
-                radix_pass(ua, ub, m, 20, s_hist[0]);
-                radix_pass(ub, ua, m, 28, s_hist[1]);
-                radix_pass(ua, ub, m, 36, s_hist[2]);
-                radix_pass(ub, ua, m, 44, s_hist[3]);
-                radix_pass(ua, ub, m, 52, s_hist[4]);
-                PHASE_STAMP(10 + (round < 7 ? round : 7) * 3);
-                m = rerank<false>(ub, sa_cur, m, ua, sa_alt, ws.isa, ws.sa);
-                PHASE_STAMP(9 + (round < 7 ? round : 7) * 3);
-            }
-            uint32_t *ts = sa_cur;
-            sa_cur = sa_alt;
-            sa_alt = ts;
-            h <<= 1;
+            seg_sort_round<true>(ua, m, nullptr, T, n, depth);
+            PHASE_STAMP(8 + round * 3);
+            m = rerank<MODE_TEXT>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out);
+            PHASE_STAMP(9 + round * 3);
+            uint64_t *tu = ua; ua = ub; ub = tu;
+            uint32_t *ts = sa_cur; sa_cur = sa_alt; sa_alt = ts;
+            depth += 8;
             round++;
         }
+        __syncthreads();
 
-        // ---- F: last column and orig_ptr
-        for (uint32_t j = tid; j < n; j += SORT_NT) {
-            const uint32_t sa = ws.sa[j];
-            L[j] = T[sa ? sa - 1 : n - 1];
-            if (sa == 0) B.blk[b].orig_ptr = j;
+        // ---- RANK rounds (deep repeats / large groups): build ISA once, then prefix doubling
+        if (m > 0 && depth < n) {
+            for (uint32_t j = tid; j < n; j += SORT_NT) ws.isa[ws.sa[j]] = j;       // resolved rotations: final rank
+            __syncthreads();
+            for (uint32_t k = tid; k < m; k += SORT_NT) {                           // unresolved: group start
+                const uint64_t rec = ua[k];
+                const uint32_t sa = (uint32_t)(rec >> TXT_SA_SHIFT) & 0xFFFFFu;
+                const uint32_t g = (uint32_t)(rec >> G_SHIFT);
+                ws.isa[sa] = g;
+                ua[k] = ((uint64_t)g << G_SHIFT) | ((uint64_t)sa << RNK_SA_SHIFT);
+            }
+            __syncthreads();
+            uint32_t h = depth;
+            while (m > 0 && h < n) {
+                const uint32_t maxgrp = s_bcast[3];
+                __syncthreads();
+                if (maxgrp <= SEG_T) {
+                    seg_sort_round<false>(ua, m, ws.isa, T, n, h);
+                    m = rerank<MODE_RANK>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out);
+                    uint64_t *tu = ua; ua = ub; ub = tu;
+                } else {
+                    gather_keys(ua, m, ws.isa, n, h);
+                    // five passes: ua -> ub -> ua -> ub -> ua -> ub
+                    radix_pass(ua, ub, m, RNK_KEY_SHIFT, s_hist[0]);
+                    radix_pass(ub, ua, m, RNK_KEY_SHIFT + 8, s_hist[1]);
+                    radix_pass(ua, ub, m, RNK_KEY_SHIFT + 16, s_hist[2]);
+                    radix_pass(ub, ua, m, RNK_KEY_SHIFT + 24, s_hist[3]);
+                    radix_pass(ua, ub, m, RNK_KEY_SHIFT + 32, s_hist[4]);
+                    m = rerank<MODE_RANK>(ub, sa_cur, m, ua, sa_alt, ws.isa, ws.sa, L, orig_out);
+                }
+                uint32_t *ts = sa_cur; sa_cur = sa_alt; sa_alt = ts;
+                h <<= 1;
+            }
+            PHASE_STAMP(4);
+            // ---- F: last column and orig_ptr from the final SA
+            for (uint32_t j = tid; j < n; j += SORT_NT) {
+                const uint32_t sa = ws.sa[j];
+                L[j] = T[sa ? sa - 1 : n - 1];
+                if (sa == 0) *orig_out = j;
+            }
         }
         PHASE_STAMP(3);
         if (tid == 0) {
