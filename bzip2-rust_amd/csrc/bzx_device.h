@@ -80,6 +80,7 @@ struct BzxBatch {
 struct BzxSplitWs {
     uint64_t *tile_rs;     // [ntiles+1] A: last run start (+1) inside the tile / after S1: carry-in run start (+1)
     uint64_t *tile_off;    // [ntiles+1] B: emitted bytes / after S2: exclusive prefix F(tile start); [ntiles] = F(len)
+    uint64_t *tile_np;     // [ntiles+1] B: 1 if the tile has a run position with k >= 3 / after S3: prefix count
     uint64_t *blk_raw;     // [max_blocks+1] raw start of every block; [nblk] = len
     uint64_t *blk_f;       // [max_blocks+1] F at the block start
     uint32_t *nblk;        // [1]

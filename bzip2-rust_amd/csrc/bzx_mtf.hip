@@ -46,9 +46,19 @@ struct Seen256 {
     }
 };
 
+#define MTF_STAMP(slot)                                                       \
+    do {                                                                      \
+        if (B.dbg && tid == 0) {                                              \
+            const unsigned long long now_ = wall_clock64();                   \
+            atomicAdd(&B.dbg[slot], now_ - t_last);                           \
+            t_last = now_;                                                    \
+        }                                                                     \
+    } while (0)
+
 __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
 {
     const uint32_t tid = threadIdx.x;
+    unsigned long long t_last = 0;
 
     for (;;) {
         if (tid == 0) m_bcast[0] = atomicAdd(&B.counters[1], 1u);
@@ -63,6 +73,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         uint8_t *__restrict__ R = B.rank + (size_t)b * BZX_BLK_STRIDE;
         uint16_t *__restrict__ V = B.mtfv + (size_t)b * BZX_BLK_STRIDE;
 
+        if (B.dbg && tid == 0) t_last = wall_clock64();
         // ---- 1. bytes in use -> dense ids (rle2_mtf.rs:26-45)
         if (tid < 256) m_inuse[tid] = 0;
         for (uint32_t i = tid; i < BZX_MAX_ALPHA + 2; i += MTF_NT) m_freq[i] = 0;
@@ -91,6 +102,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         }
         __syncthreads();
 
+        MTF_STAMP(32);
         // ---- 2. chunking: at most 512 chunks, list stride = nInUse bytes, lists fit 72 KiB
         uint32_t nch = MTF_LIST_BYTES / n_in_use;
         if (nch > MTF_NT) nch = MTF_NT;
@@ -117,6 +129,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         }
         __syncthreads();
 
+        MTF_STAMP(33);
         // ---- 4. MTF list at my chunk start: walk the earlier chunks backwards
         if (have_chunk) {
             Seen256 seen;
@@ -138,6 +151,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         }
         __syncthreads();
 
+        MTF_STAMP(34);
         // ---- 5. plain MTF over my chunk (rle2_mtf.rs:61-138), rank bytes to HBM
         if (have_chunk) {
             uint8_t *lst = m_list + tid * stride;
@@ -174,6 +188,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         }
         __syncthreads();
 
+        MTF_STAMP(35);
         // ---- 6. zero-run coding + symbol emission + histogram (rle2_mtf.rs:63-172)
         if (tid == 0) {
             m_bcast[1] = 0;
@@ -243,6 +258,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
             }
             __syncthreads();
         }
+        MTF_STAMP(36);
         // trailing zero run + EOB
         if (tid == 0) {
             uint32_t o = m_bcast[2];

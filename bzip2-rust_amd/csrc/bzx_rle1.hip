@@ -157,8 +157,9 @@ __global__ __launch_bounds__(1024) void bzx_rl_scan_kernel(uint64_t *v, uint64_t
 // Emission analysis of my 32 bytes: e[i] in {0,1,2} packed 2 bits each; returns my emitted byte count.
 // rs_in = run start (+1) carried into the tile (0 = none, only possible at p == 0).
 __device__ __forceinline__ uint32_t lane_emission(const TileLane &t, uint64_t rs_in_plus1, uint64_t &e_bits,
-                                                  uint32_t &k_first)
+                                                  uint32_t &k_first, bool &any_long)
 {
+    any_long = false;
     // run start for my first byte: either inside earlier lanes of the tile / earlier tiles (rs_in) or my own byte
     uint32_t k = 0;
     if (t.nvalid) {
@@ -175,6 +176,7 @@ __device__ __forceinline__ uint32_t lane_emission(const TileLane &t, uint64_t rs
             if (c != prev) k = 0;
             if (i == 0) k_first = k;
             const uint32_t e = k < 3 ? 1u : (k == 3 ? 2u : 0u);
+            if (k >= 3) any_long = true;
             bits |= (uint64_t)e << (2 * i);
             cnt += e;
             k = (k + 1 == 255) ? 0 : k + 1;
@@ -192,6 +194,7 @@ struct TileInfo {
     uint32_t k_first;
     uint32_t f_excl;     // emitted bytes of the tile before my first byte
     uint32_t f_total;    // emitted bytes of the whole tile
+    bool any_long;       // my bytes contain a run position with k >= 3 (RLE1 is not the identity here)
 };
 
 __device__ __forceinline__ void tile_analyse(const uint8_t *__restrict__ raw, uint64_t len, uint64_t tile,
@@ -202,7 +205,7 @@ __device__ __forceinline__ void tile_analyse(const uint8_t *__restrict__ raw, ui
     const uint64_t rs_prev = block_excl_max64(lane_last_rs(ti.t), scratch64, tot);
     const uint64_t carry = ws.tile_rs[tile];
     const uint64_t rs_in = rs_prev ? rs_prev : carry;
-    const uint32_t cnt = lane_emission(ti.t, rs_in, ti.e_bits, ti.k_first);
+    const uint32_t cnt = lane_emission(ti.t, rs_in, ti.e_bits, ti.k_first, ti.any_long);
     ti.f_excl = bzx_block_excl_sum<RL_NT>(cnt, scratch32, ti.f_total);
 }
 
@@ -215,7 +218,11 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_count_kernel(const uint8_t *__re
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         TileInfo ti;
         tile_analyse(raw, len, tile, ws, s64, s32, ti);
-        if (threadIdx.x == 0) ws.tile_off[tile] = ti.f_total;
+        const bool np = __syncthreads_or(ti.any_long);
+        if (threadIdx.x == 0) {
+            ws.tile_off[tile] = ti.f_total;
+            ws.tile_np[tile] = np ? 1 : 0;
+        }
         __syncthreads();
     }
 }
@@ -257,6 +264,33 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_boundaries_kernel(const uint8_t 
             start = len;
             f_start = f_len;
             break;
+        }
+        // ---- fast path: RLE1 is the identity on every tile this block can touch (no run position k >= 3),
+        // so F(x) - F(start) = x - start and the boundary is the end of the piece around start + nmax.
+        {
+            const uint64_t x = start + nmax;
+            const uint64_t t0 = start / RL_TILE;
+            uint64_t t1 = x / RL_TILE + 2;
+            if (t1 > ntiles) t1 = ntiles;
+            if (x + 4 < len && x >= 4 && ws.tile_np[t1] == ws.tile_np[t0]) {
+                uint8_t w[8];
+                __builtin_memcpy(w, raw + x - 4, 8);        // bytes x-4 .. x+3
+                // k(x) = equal bytes immediately before x (runs are <= 3 long here)
+                uint32_t k = 0;
+                while (k < 3 && w[3 - k] == w[4]) k++;
+                uint64_t q = x;
+                if (k) {
+                    q = x + 1;
+                    uint32_t kk = k + 1;
+                    while (kk < 4 && q < x + 4 && w[4 + (q - x)] == w[4]) {
+                        q++;
+                        kk++;
+                    }
+                }
+                start = q;
+                f_start = f_start + (q - (x - nmax));
+                continue;
+            }
         }
         // largest tile with F(tile start) < target   (tile_off is non-decreasing; tile_off[0] = 0 < target)
         uint64_t lo = 0, hi = ntiles;   // invariant: tile_off[lo] < target; hi = first tile with tile_off >= target or ntiles
@@ -435,15 +469,23 @@ __device__ uint32_t gf_xpow8(uint64_t nbytes)
 __global__ __launch_bounds__(CRC_NT) void bzx_rl_crc_kernel(const uint8_t *__restrict__ raw, BzxSplitWs ws,
                                                             BzxBlock *__restrict__ blk)
 {
-    __shared__ uint32_t tab[256];
+    // slicing-by-8 tables: tab[k][v] = register after byte v followed by k zero bytes (from a zero register)
+    __shared__ uint32_t tab[8][256];
     __shared__ uint32_t part[CRC_NT];
     const uint32_t tid = threadIdx.x;
     if (tid < 256) {
         uint32_t c = tid << 24;
         for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : (c << 1);
-        tab[tid] = c;
+        tab[0][tid] = c;
     }
     __syncthreads();
+    for (int k = 1; k < 8; k++) {
+        if (tid < 256) {
+            const uint32_t p = tab[k - 1][tid];
+            tab[k][tid] = (p << 8) ^ tab[0][p >> 24];
+        }
+        __syncthreads();
+    }
     const uint32_t nblk = ws.nblk[0];
     for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x) {
         const uint64_t lo = ws.blk_raw[b], hi = ws.blk_raw[b + 1];
@@ -452,11 +494,18 @@ __global__ __launch_bounds__(CRC_NT) void bzx_rl_crc_kernel(const uint8_t *__res
         const uint64_t a = lo + (uint64_t)tid * per < hi ? lo + (uint64_t)tid * per : hi;
         const uint64_t e = a + per < hi ? a + per : hi;
         uint32_t r = 0;
-        for (uint64_t p = a; p < e; p++) r = (r << 8) ^ tab[(r >> 24) ^ raw[p]];
+        uint64_t p = a;
+        for (; p + 8 <= e; p += 8) {
+            uint64_t w;
+            __builtin_memcpy(&w, raw + p, 8);                 // unaligned 8-byte load
+            const uint32_t w0 = __builtin_bswap32((uint32_t)w) ^ r, w1 = __builtin_bswap32((uint32_t)(w >> 32));
+            r = tab[7][w0 >> 24] ^ tab[6][(w0 >> 16) & 255u] ^ tab[5][(w0 >> 8) & 255u] ^ tab[4][w0 & 255u] ^
+                tab[3][w1 >> 24] ^ tab[2][(w1 >> 16) & 255u] ^ tab[1][(w1 >> 8) & 255u] ^ tab[0][w1 & 255u];
+        }
+        for (; p < e; p++) r = (r << 8) ^ tab[0][(r >> 24) ^ raw[p]];
         part[tid] = r;
         __syncthreads();
-        // chunk i has length len_i; state = state * x^(8 len_i) + r_i, folded as a tree with equal-length halves
-        // except for the tail: do the simple serial fold by one wave-free lane over 1024 entries (cheap).
+        // fold: state = state * x^(8 len_i) + r_i over the 1024 chunks (GF(2) polynomial arithmetic mod P)
         if (tid == 0) {
             uint32_t s = 0xffffffffu;
             const uint32_t xp = gf_xpow8(per);
@@ -483,14 +532,15 @@ int bzx_split_launch_boundaries(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, 
                                 BzxSplitWs *ws_out)
 {
     const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE;
-    const size_t bytes = (2 * (ntiles + 2) + 2 * ((size_t)max_blocks + 2)) * sizeof(uint64_t) + 64;
+    const size_t bytes = (3 * (ntiles + 2) + 2 * ((size_t)max_blocks + 2)) * sizeof(uint64_t) + 64;
     void *p = nullptr;
     int rc = bzx_ctx_split_scratch(ctx, bytes, &p);
     if (rc) return rc;
     BzxSplitWs ws;
     ws.tile_rs = (uint64_t *)p;
     ws.tile_off = ws.tile_rs + (ntiles + 2);
-    ws.blk_raw = ws.tile_off + (ntiles + 2);
+    ws.tile_np = ws.tile_off + (ntiles + 2);
+    ws.blk_raw = ws.tile_np + (ntiles + 2);
     ws.blk_f = ws.blk_raw + (max_blocks + 2);
     ws.nblk = (uint32_t *)(ws.blk_f + (max_blocks + 2));
     ws.max_blocks = max_blocks;
@@ -501,6 +551,7 @@ int bzx_split_launch_boundaries(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, 
     hipLaunchKernelGGL(bzx_rl_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_rs, ntiles, 1);
     hipLaunchKernelGGL(bzx_rl_count_kernel, dim3(grid), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, ws);
     hipLaunchKernelGGL(bzx_rl_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_off, ntiles, 0);
+    hipLaunchKernelGGL(bzx_rl_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_np, ntiles, 0);
     hipLaunchKernelGGL(bzx_rl_boundaries_kernel, dim3(1), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, nmax, ws);
     *ws_out = ws;
     return 0;

@@ -183,3 +183,13 @@ inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 
 struct uint2 { unsigned x, y; };
 inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r = {x, y}; return r; }
 inline unsigned long long wall_clock64() { return 0; }
+inline int __syncthreads_or(int p)
+{
+    static int acc;
+    __syncthreads();
+    if (threadIdx.x == 0) acc = 0;
+    __syncthreads();
+    if (p) acc = 1;
+    __syncthreads();
+    return acc;
+}

@@ -12,13 +12,13 @@ blk = o.synthtext(899981) if kind == "text" else o.randbytes(899981)
 ms = (C.c_float * 4)(); t = (C.c_ulonglong * 64)()
 lib._check(L.bzx_dbg_time_stages(lib.ctx, blk, len(blk), reps, 1, ms))
 lib._check(L.bzx_dbg_phase_timers(lib.ctx, 1, None))
-lib._check(L.bzx_dbg_time_stages(lib.ctx, blk, len(blk), reps, 1, ms))
+lib._check(L.bzx_dbg_time_stages(lib.ctx, blk, len(blk), reps, 15, ms))
 lib._check(L.bzx_dbg_phase_timers(lib.ctx, 0, t))
-names = {0: "I1 build", 1: "I2 4 radix passes", 2: "R0 rerank", 3: "F final gather"}
+names = {32: "MTF in-use", 33: "MTF recency lists", 34: "MTF start lists", 35: "MTF ranks", 36: "MTF zero-run + emit", 0: "I1 build", 1: "I2 4 radix passes", 2: "R0 rerank", 3: "F final gather"}
 for r in range(8):
     names[8 + 3 * r] = f"round{r} seg sort"; names[9 + 3 * r] = f"round{r} rerank"; names[10 + 3 * r] = f"round{r} gather+5 passes"
 tot = sum(t)
-print(f"bwt kernel {ms[0]:.2f} ms for {reps} blocks; phase ticks summed over blocks (per block ms = ticks/100e3/reps):")
+print(f"bwt {ms[0]:.2f} mtf {ms[1]:.2f} huf {ms[2]:.2f} emit {ms[3]:.2f} ms for {reps} blocks; phase ticks summed over blocks (per block ms = ticks/100e3/reps):")
 for i in range(64):
     if t[i]:
         print(f"  {names.get(i, i):28s} {t[i] / 100e3 / reps:8.3f} ms/block  {100.0 * t[i] / tot:5.1f}%")
