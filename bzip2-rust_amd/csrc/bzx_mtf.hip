@@ -18,8 +18,8 @@
 #define MTF_LIST_BYTES (72 * 1024)
 #define MTF_E 16
 
-__shared__ uint8_t m_rec[MTF_LIST_BYTES];    // per-chunk recency lists (most recent first)
-__shared__ uint8_t m_list[MTF_LIST_BYTES];   // per-chunk working MTF lists
+__shared__ __attribute__((aligned(16))) uint8_t m_rec[MTF_LIST_BYTES];    // per-chunk recency lists (most recent first)
+__shared__ __attribute__((aligned(16))) uint8_t m_list[MTF_LIST_BYTES];   // per-chunk working MTF lists
 __shared__ uint16_t m_reccnt[MTF_NT];
 __shared__ uint32_t m_inuse[256];
 __shared__ uint8_t m_seq[256];
@@ -103,13 +103,14 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         __syncthreads();
 
         MTF_STAMP(32);
-        // ---- 2. chunking: at most 512 chunks, list stride = nInUse bytes, lists fit 72 KiB
-        uint32_t nch = MTF_LIST_BYTES / n_in_use;
+        // ---- 2. chunking: at most 512 chunks; a list is stride64 (odd) 8-byte words per chunk, lists fit 72 KiB
+        const uint32_t stride64 = ((n_in_use + 7) / 8) | 1u;      // odd word stride: conflict-free 64-bit LDS access
+        const uint32_t stride = stride64 * 8;
+        uint32_t nch = MTF_LIST_BYTES / stride;
         if (nch > MTF_NT) nch = MTF_NT;
         uint32_t csz = (n + nch - 1) / nch;
         csz = (csz + 15u) & ~15u;
         const uint32_t nch_used = (n + csz - 1) / csz;
-        const uint32_t stride = n_in_use;
         const uint32_t c_lo = tid * csz;
         const uint32_t c_hi = (c_lo + csz < n) ? c_lo + csz : n;
         const bool have_chunk = tid < nch_used;
@@ -120,16 +121,29 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
             seen.clear();
             uint32_t cnt = 0;
             uint8_t *rec = m_rec + tid * stride;
-            for (uint32_t i = c_hi; i > c_lo && cnt < n_in_use;) {
-                i--;
-                const uint32_t s = m_seq[L[i]];
-                if (!seen.test_set(s)) rec[cnt++] = (uint8_t)s;
+            // 16 bytes per load, walking backwards (chunk starts are 16-byte aligned, slabs 256-byte aligned)
+            for (uint32_t i0 = (c_hi - 1) & ~15u; cnt < n_in_use;) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(L + i0);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 3; q >= 0; q--) {
+#pragma unroll
+                    for (int k = 3; k >= 0; k--) {
+                        const uint32_t i = i0 + (uint32_t)(q * 4 + k);
+                        if (i < c_hi) {
+                            const uint32_t s = m_seq[(w[q] >> (8 * k)) & 255u];
+                            if (!seen.test_set(s)) rec[cnt++] = (uint8_t)s;
+                        }
+                    }
+                }
+                if (i0 == c_lo) break;
+                i0 -= 16;
             }
             m_reccnt[tid] = (uint16_t)cnt;
         }
         __syncthreads();
-
         MTF_STAMP(33);
+
         // ---- 4. MTF list at my chunk start: walk the earlier chunks backwards
         if (have_chunk) {
             Seen256 seen;
@@ -148,18 +162,21 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
             // symbols never seen so far keep the initial (ascending) order
             for (uint32_t s = 0; s < n_in_use && cnt < n_in_use; s++)
                 if (!seen.test(s)) lst[cnt++] = (uint8_t)s;
+            for (; cnt < stride; cnt++) lst[cnt] = 0xff;           // padding never matches before a real entry
         }
         __syncthreads();
-
         MTF_STAMP(34);
-        // ---- 5. plain MTF over my chunk (rle2_mtf.rs:61-138), rank bytes to HBM
+
+        // ---- 5. plain MTF over my chunk (rle2_mtf.rs:61-138), rank bytes to HBM.
+        // The first 8 list entries live in a register (byte 0 = front); deeper entries in LDS as 8-byte words,
+        // searched and shifted one word at a time.
         if (have_chunk) {
-            uint8_t *lst = m_list + tid * stride;
-            uint32_t front = lst[0];
+            uint64_t *lst64 = reinterpret_cast<uint64_t *>(m_list + tid * stride);
+            uint64_t w = lst64[0];
+            const uint64_t ones = 0x0101010101010101ull, highs = 0x8080808080808080ull;
             for (uint32_t i0 = c_lo; i0 < c_hi; i0 += 16) {
-                // csz is a multiple of 16 and slabs are 256-byte aligned: 16-byte loads/stores are aligned
                 const uint4 v = *reinterpret_cast<const uint4 *>(L + i0);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
                 uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -167,19 +184,41 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
                     for (int k = 0; k < 4; k++) {
                         const uint32_t i = i0 + q * 4 + k;
                         if (i < c_hi) {
-                            const uint32_t s = m_seq[(w[q] >> (8 * k)) & 255u];
-                            uint32_t j = 0;
-                            if (s != front) {
-                                uint32_t tmp = front;
-                                do {
-                                    j++;
-                                    const uint32_t t2 = tmp;
-                                    tmp = lst[j];
-                                    lst[j] = (uint8_t)t2;
-                                } while (tmp != s);
-                                front = s;
+                            const uint64_t s = m_seq[(wd[q] >> (8 * k)) & 255u];
+                            const uint64_t sp = s * ones;
+                            uint64_t x = w ^ sp;
+                            uint64_t z = (x - ones) & ~x & highs;
+                            uint32_t rank;
+                            if (z) {
+                                const uint32_t j = (uint32_t)(__ffsll((unsigned long long)z) - 1) >> 3;
+                                rank = j;
+                                if (j) {
+                                    const uint64_t lowmask = (1ull << (8 * j)) - 1ull;
+                                    const uint64_t himask = j == 7 ? 0ull : (~0ull << (8 * (j + 1)));
+                                    w = (w & himask) | ((w & lowmask) << 8) | s;
+                                }
+                            } else {
+                                uint64_t carry = w >> 56;
+                                w = (w << 8) | s;
+                                uint32_t qq = 1;
+                                for (;;) {
+                                    const uint64_t c = lst64[qq];
+                                    x = c ^ sp;
+                                    z = (x - ones) & ~x & highs;
+                                    if (z) {
+                                        const uint32_t j = (uint32_t)(__ffsll((unsigned long long)z) - 1) >> 3;
+                                        const uint64_t lowmask = j ? ((1ull << (8 * j)) - 1ull) : 0ull;
+                                        const uint64_t himask = j == 7 ? 0ull : (~0ull << (8 * (j + 1)));
+                                        lst64[qq] = (c & himask) | ((c & lowmask) << 8) | carry;
+                                        rank = 8 * qq + j;
+                                        break;
+                                    }
+                                    lst64[qq] = (c << 8) | carry;
+                                    carry = c >> 56;
+                                    qq++;
+                                }
                             }
-                            o[q] |= j << (8 * k);
+                            o[q] |= rank << (8 * k);
                         }
                     }
                 }
@@ -187,7 +226,6 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
             }
         }
         __syncthreads();
-
         MTF_STAMP(35);
         // ---- 6. zero-run coding + symbol emission + histogram (rle2_mtf.rs:63-172)
         if (tid == 0) {
