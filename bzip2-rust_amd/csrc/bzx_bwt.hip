@@ -67,9 +67,25 @@ __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t d, bool valid)
     }
 }
 
+// INIT record of rotation i: [first 4 block bytes:32 @28 | i:20 @8 | preceding byte:8 @0]
+__device__ __forceinline__ uint64_t init_record(const uint8_t *__restrict__ T, uint32_t n, uint32_t i)
+{
+    uint32_t key = 0, p = i;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        key = (key << 8) | T[p];
+        p++;
+        if (p >= n) p = 0;
+    }
+    const uint32_t prev = T[i ? i - 1 : n - 1];
+    return ((uint64_t)key << TXT_KEY_SHIFT) | ((uint64_t)i << TXT_SA_SHIFT) | (uint64_t)prev;
+}
+
 // One stable LSD pass: src[0..m) -> dst by the 8-bit digit at `shift`; hist = digit histogram (LDS).
+// FROM_TEXT: the source records are generated on the fly from the block bytes (first pass of the initial sort).
+template <bool FROM_TEXT>
 __device__ void radix_pass(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint32_t m, int shift,
-                           const uint32_t *hist)
+                           const uint32_t *hist, const uint8_t *__restrict__ T = nullptr)
 {
     const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
     uint32_t tot;
@@ -88,7 +104,7 @@ __device__ void radix_pass(const uint64_t *__restrict__ src, uint64_t *__restric
 #pragma unroll
         for (int e = 0; e < SORT_E; e++) {
             const uint32_t idx = wbase + e * 64 + lane;
-            rec[e] = idx < m ? src[idx] : 0ull;
+            rec[e] = idx < m ? (FROM_TEXT ? init_record(T, m, idx) : src[idx]) : 0ull;
         }
         uint32_t *wc = &s_wcnt[cur][wave * 256];
 #pragma unroll
@@ -479,24 +495,13 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         uint8_t *__restrict__ L = B.bwt + (size_t)b * BZX_BLK_STRIDE;
         if (B.dbg && tid == 0) t_last = wall_clock64();
 
-        // ---- I1: records [first 4 bytes | i | preceding byte] and their four digit histograms
+        // ---- I1: four digit histograms of the INIT records (the records themselves are built by pass 1)
         for (uint32_t i = tid; i < 4 * 256; i += SORT_NT) (&s_hist[0][0])[i] = 0;
         __syncthreads();
         for (uint32_t t0 = 0; t0 < n; t0 += SORT_NT) {
             const uint32_t i = t0 + tid;
             const bool valid = i < n;
-            uint32_t key = 0;
-            if (valid) {
-                uint32_t p = i;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    key = (key << 8) | T[p];
-                    p++;
-                    if (p >= n) p = 0;
-                }
-                const uint32_t prev = T[i ? i - 1 : n - 1];
-                ws.u0[i] = ((uint64_t)key << TXT_KEY_SHIFT) | ((uint64_t)i << TXT_SA_SHIFT) | (uint64_t)prev;
-            }
+            const uint32_t key = valid ? (uint32_t)(init_record(T, n, i) >> TXT_KEY_SHIFT) : 0u;
 #pragma unroll
             for (int p = 0; p < 4; p++) hist_add(s_hist[p], (key >> (8 * p)) & 255u, valid);
         }
@@ -504,17 +509,17 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         PHASE_STAMP(0);
 
         // ---- I2: four LSD passes over the 32-bit key (record bits 28..59)
-        radix_pass(ws.u0, ws.u1, n, TXT_KEY_SHIFT, s_hist[0]);
-        radix_pass(ws.u1, ws.u0, n, TXT_KEY_SHIFT + 8, s_hist[1]);
-        radix_pass(ws.u0, ws.u1, n, TXT_KEY_SHIFT + 16, s_hist[2]);
-        radix_pass(ws.u1, ws.u0, n, TXT_KEY_SHIFT + 24, s_hist[3]);
+        radix_pass<true>(nullptr, ws.u0, n, TXT_KEY_SHIFT, s_hist[0], T);
+        radix_pass<false>(ws.u0, ws.u1, n, TXT_KEY_SHIFT + 8, s_hist[1]);
+        radix_pass<false>(ws.u1, ws.u0, n, TXT_KEY_SHIFT + 16, s_hist[2]);
+        radix_pass<false>(ws.u0, ws.u1, n, TXT_KEY_SHIFT + 24, s_hist[3]);
         PHASE_STAMP(1);
 
         // ---- R: ranks by the first four bytes
-        uint64_t *ua = ws.u1, *ub = ws.u0;      // ua: current compacted records, ub: the other buffer
+        uint64_t *ua = ws.u0, *ub = ws.u1;      // ua: current compacted records, ub: the other buffer
         uint32_t *sa_cur = ws.s0, *sa_alt = ws.s1;
         uint32_t *orig_out = &B.blk[b].orig_ptr;
-        uint32_t m = rerank<MODE_INIT>(ws.u0, nullptr, n, ua, sa_cur, ws.isa, ws.sa, L, orig_out);
+        uint32_t m = rerank<MODE_INIT>(ws.u1, nullptr, n, ua, sa_cur, ws.isa, ws.sa, L, orig_out);
         PHASE_STAMP(2);
 
         // ---- TEXT rounds: 8 more block bytes per round, tiles only
@@ -555,11 +560,11 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
                 } else {
                     gather_keys(ua, m, ws.isa, n, h);
                     // five passes: ua -> ub -> ua -> ub -> ua -> ub
-                    radix_pass(ua, ub, m, RNK_KEY_SHIFT, s_hist[0]);
-                    radix_pass(ub, ua, m, RNK_KEY_SHIFT + 8, s_hist[1]);
-                    radix_pass(ua, ub, m, RNK_KEY_SHIFT + 16, s_hist[2]);
-                    radix_pass(ub, ua, m, RNK_KEY_SHIFT + 24, s_hist[3]);
-                    radix_pass(ua, ub, m, RNK_KEY_SHIFT + 32, s_hist[4]);
+                    radix_pass<false>(ua, ub, m, RNK_KEY_SHIFT, s_hist[0]);
+                    radix_pass<false>(ub, ua, m, RNK_KEY_SHIFT + 8, s_hist[1]);
+                    radix_pass<false>(ua, ub, m, RNK_KEY_SHIFT + 16, s_hist[2]);
+                    radix_pass<false>(ub, ua, m, RNK_KEY_SHIFT + 24, s_hist[3]);
+                    radix_pass<false>(ua, ub, m, RNK_KEY_SHIFT + 32, s_hist[4]);
                     m = rerank<MODE_RANK>(ub, sa_cur, m, ua, sa_alt, ws.isa, ws.sa, L, orig_out);
                 }
                 uint32_t *ts = sa_cur; sa_cur = sa_alt; sa_alt = ts;
@@ -576,7 +581,10 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         PHASE_STAMP(3);
         if (tid == 0) {
             B.blk[b].status = (m > 0) ? BZX_ST_PERIODIC : 0u;
-            if (m > 0) B.plist[atomicAdd(&B.counters[5], 1u)] = b;   // tie order fixed up by bzx_periodic.hip
+            if (m > 0) {
+                B.blk[b].pad_[0] = s_bcast[3];                       // copies of every rotation (k of u^k)
+                B.plist[atomicAdd(&B.counters[5], 1u)] = b;          // tie order fixed up by bzx_periodic.hip
+            }
         }
         __syncthreads();
     }
