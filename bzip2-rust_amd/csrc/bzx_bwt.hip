@@ -50,6 +50,8 @@ __shared__ uint32_t s_hist[5][256];
 __shared__ uint32_t s_base[256];
 __shared__ uint32_t s_wcnt[2][SORT_NW * 256];
 __shared__ uint32_t s_scratch[2 * SORT_NW];
+__shared__ uint8_t s_seq[256];     // byte value -> dense symbol id (order preserving)
+__shared__ uint32_t s_inuse[256];
 __shared__ uint32_t s_bcast[4];   // [0] block index, [1] carry group start (+1), [2] carry count, [3] largest group
 
 // Add one to hist[d]; when the whole wave holds the same digit a single lane adds the count.
@@ -67,16 +69,44 @@ __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t d, bool valid)
     }
 }
 
-// INIT record of rotation i: [first 4 block bytes:32 @28 | i:20 @8 | preceding byte:8 @0]
-__device__ __forceinline__ uint64_t init_record(const uint8_t *__restrict__ T, uint32_t n, uint32_t i)
+// 8 block bytes starting at cyclic position p (p < n), big-endian
+__device__ __forceinline__ uint64_t text_key8(const uint8_t *__restrict__ T, uint32_t n, uint32_t p)
 {
-    uint32_t key = 0, p = i;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        key = (key << 8) | T[p];
+    if (p + 8 <= n) {
+        uint64_t w;
+        __builtin_memcpy(&w, T + p, 8);      // unaligned 8-byte global load
+        return __builtin_bswap64(w);
+    }
+    uint64_t w = 0;
+    for (int j = 0; j < 8; j++) {
+        w = (w << 8) | T[p];
         p++;
         if (p >= n) p = 0;
     }
+    return w;
+}
+
+
+// Alphabet packing: the block's bytes are mapped to dense ids (s_seq) of `bits` bits each, so a 32-bit
+// initial key holds ksym = min(8, 32/bits) symbols (6 for ordinary text) instead of 4 bytes, and a 64-bit
+// round key holds up to 16.  Fixed-width ids keep integer order == lexicographic order.
+__device__ __forceinline__ uint32_t pack_symbols32(uint64_t w, uint32_t bits, uint32_t ksym)
+{
+    uint32_t sy[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) sy[j] = s_seq[(uint32_t)(w >> (56 - 8 * j)) & 255u];   // independent LDS reads
+    uint32_t key = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if ((uint32_t)j < ksym) key = (key << bits) | sy[j];
+    return key;
+}
+
+// INIT record of rotation i: [first ksym symbols:32 @28 | i:20 @8 | preceding byte:8 @0]
+__device__ __forceinline__ uint64_t init_record(const uint8_t *__restrict__ T, uint32_t n, uint32_t i, uint32_t bits,
+                                                uint32_t ksym)
+{
+    const uint32_t key = pack_symbols32(text_key8(T, n, i), bits, ksym);
     const uint32_t prev = T[i ? i - 1 : n - 1];
     return ((uint64_t)key << TXT_KEY_SHIFT) | ((uint64_t)i << TXT_SA_SHIFT) | (uint64_t)prev;
 }
@@ -85,7 +115,8 @@ __device__ __forceinline__ uint64_t init_record(const uint8_t *__restrict__ T, u
 // FROM_TEXT: the source records are generated on the fly from the block bytes (first pass of the initial sort).
 template <bool FROM_TEXT>
 __device__ void radix_pass(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint32_t m, int shift,
-                           const uint32_t *hist, const uint8_t *__restrict__ T = nullptr)
+                           const uint32_t *hist, const uint8_t *__restrict__ T = nullptr, uint32_t bits = 8,
+                           uint32_t ksym = 4)
 {
     const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
     uint32_t tot;
@@ -104,7 +135,7 @@ __device__ void radix_pass(const uint64_t *__restrict__ src, uint64_t *__restric
 #pragma unroll
         for (int e = 0; e < SORT_E; e++) {
             const uint32_t idx = wbase + e * 64 + lane;
-            rec[e] = idx < m ? (FROM_TEXT ? init_record(T, m, idx) : src[idx]) : 0ull;
+            rec[e] = idx < m ? (FROM_TEXT ? init_record(T, m, idx, bits, ksym) : src[idx]) : 0ull;
         }
         uint32_t *wc = &s_wcnt[cur][wave * 256];
 #pragma unroll
@@ -351,27 +382,11 @@ __device__ __forceinline__ uint32_t seg_align(const uint64_t *__restrict__ U, ui
     return best;
 }
 
-// 8 block bytes starting at cyclic position p (p < n), big-endian
-__device__ __forceinline__ uint64_t text_key8(const uint8_t *__restrict__ T, uint32_t n, uint32_t p)
-{
-    if (p + 8 <= n) {
-        uint64_t w;
-        __builtin_memcpy(&w, T + p, 8);      // unaligned 8-byte global load
-        return __builtin_bswap64(w);
-    }
-    uint64_t w = 0;
-    for (int j = 0; j < 8; j++) {
-        w = (w << 8) | T[p];
-        p++;
-        if (p >= n) p = 0;
-    }
-    return w;
-}
-
 // TEXT: key = block bytes [sa+h, sa+h+8) ; RANK: key2 = ISA[(sa+h) mod n] merged into the record.
 template <bool TEXT>
 __device__ void seg_sort_round(uint64_t *__restrict__ U, uint32_t m, const uint32_t *__restrict__ ISA,
-                               const uint8_t *__restrict__ T, uint32_t n, uint32_t h)
+                               const uint8_t *__restrict__ T, uint32_t n, uint32_t h, uint32_t bits = 8,
+                               uint32_t csym = 8)
 {
     const uint32_t lane = bzx_lane(), wave = bzx_wave();
     const uint32_t share = (m + SORT_NW - 1) / SORT_NW;
@@ -416,7 +431,24 @@ __device__ void seg_sort_round(uint64_t *__restrict__ U, uint32_t m, const uint3
                 if (TEXT) {
                     uint32_t p = ((uint32_t)(v[j].rec >> TXT_SA_SHIFT) & 0xFFFFFu) + hmod;
                     if (p >= n) p -= n;
-                    v[j].key = text_key8(T, n, p);
+                    const uint64_t w0 = text_key8(T, n, p);
+                    uint64_t w1 = 0;
+                    if (csym > 8) {
+                        uint32_t p2 = p + 8;
+                        while (p2 >= n) p2 -= n;
+                        w1 = text_key8(T, n, p2);
+                    }
+                    uint32_t sy[16];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        sy[q] = s_seq[(uint32_t)(w0 >> (56 - 8 * q)) & 255u];
+                        sy[q + 8] = s_seq[(uint32_t)(w1 >> (56 - 8 * q)) & 255u];
+                    }
+                    uint64_t key = 0;
+#pragma unroll
+                    for (int q = 0; q < 16; q++)
+                        if ((uint32_t)q < csym) key = (key << bits) | (uint64_t)sy[q];
+                    v[j].key = key;
                     v[j].rec &= ~(0x3FFull << TXT_KEY_SHIFT);     // clear the tile-local slot of the last round
                 } else {
                     uint32_t p = ((uint32_t)(v[j].rec >> RNK_SA_SHIFT) & 0xFFFFFu) + hmod;
@@ -495,13 +527,30 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         uint8_t *__restrict__ L = B.bwt + (size_t)b * BZX_BLK_STRIDE;
         if (B.dbg && tid == 0) t_last = wall_clock64();
 
+        // ---- A: bytes in use -> dense symbol ids; symbols per key
+        if (tid < 256) s_inuse[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += SORT_NT) s_inuse[T[i]] = 1;
+        __syncthreads();
+        uint32_t n_in_use;
+        {
+            const uint32_t flag = tid < 256 ? s_inuse[tid] : 0u;
+            const uint32_t ex = bzx_block_excl_sum<SORT_NT>(flag, s_scratch, n_in_use);
+            if (tid < 256) s_seq[tid] = (uint8_t)ex;
+        }
+        __syncthreads();
+        uint32_t bits = 1;
+        while ((1u << bits) < n_in_use) bits++;
+        const uint32_t ksym = 32 / bits < 8 ? 32 / bits : 8;          // symbols in the 32-bit initial key
+        const uint32_t csym = 64 / bits < 16 ? 64 / bits : 16;        // symbols in a 64-bit round key
+
         // ---- I1: four digit histograms of the INIT records (the records themselves are built by pass 1)
         for (uint32_t i = tid; i < 4 * 256; i += SORT_NT) (&s_hist[0][0])[i] = 0;
         __syncthreads();
         for (uint32_t t0 = 0; t0 < n; t0 += SORT_NT) {
             const uint32_t i = t0 + tid;
             const bool valid = i < n;
-            const uint32_t key = valid ? (uint32_t)(init_record(T, n, i) >> TXT_KEY_SHIFT) : 0u;
+            const uint32_t key = valid ? pack_symbols32(text_key8(T, n, i), bits, ksym) : 0u;
 #pragma unroll
             for (int p = 0; p < 4; p++) hist_add(s_hist[p], (key >> (8 * p)) & 255u, valid);
         }
@@ -509,7 +558,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         PHASE_STAMP(0);
 
         // ---- I2: four LSD passes over the 32-bit key (record bits 28..59)
-        radix_pass<true>(nullptr, ws.u0, n, TXT_KEY_SHIFT, s_hist[0], T);
+        radix_pass<true>(nullptr, ws.u0, n, TXT_KEY_SHIFT, s_hist[0], T, bits, ksym);
         radix_pass<false>(ws.u0, ws.u1, n, TXT_KEY_SHIFT + 8, s_hist[1]);
         radix_pass<false>(ws.u1, ws.u0, n, TXT_KEY_SHIFT + 16, s_hist[2]);
         radix_pass<false>(ws.u0, ws.u1, n, TXT_KEY_SHIFT + 24, s_hist[3]);
@@ -522,17 +571,17 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         uint32_t m = rerank<MODE_INIT>(ws.u1, nullptr, n, ua, sa_cur, ws.isa, ws.sa, L, orig_out);
         PHASE_STAMP(2);
 
-        // ---- TEXT rounds: 8 more block bytes per round, tiles only
-        uint32_t depth = 4, round = 0;
+        // ---- TEXT rounds: csym more symbols per round, tiles only
+        uint32_t depth = ksym, round = 0;
         while (m > 0 && depth < n && round < TEXT_ROUNDS && s_bcast[3] <= SEG_T) {
             __syncthreads();
-            seg_sort_round<true>(ua, m, nullptr, T, n, depth);
+            seg_sort_round<true>(ua, m, nullptr, T, n, depth, bits, csym);
             PHASE_STAMP(8 + round * 3);
             m = rerank<MODE_TEXT>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out);
             PHASE_STAMP(9 + round * 3);
             uint64_t *tu = ua; ua = ub; ub = tu;
             uint32_t *ts = sa_cur; sa_cur = sa_alt; sa_alt = ts;
-            depth += 8;
+            depth += csym;
             round++;
         }
         __syncthreads();
