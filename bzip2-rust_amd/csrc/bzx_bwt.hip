@@ -128,14 +128,30 @@ __device__ void radix_pass(const uint64_t *__restrict__ src, uint64_t *__restric
 
     int cur = 0;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    // software pipeline: the records of tile t+1 are loaded while tile t is ranked and scattered; the
+    // barriers inside the loop order LDS only, so those loads (and the scatter stores) stay in flight.
+    uint64_t nxt[SORT_E];
+    {
+        const uint32_t wbase = wave * (64 * SORT_E);
+#pragma unroll
+        for (int e = 0; e < SORT_E; e++) {
+            const uint32_t idx = wbase + e * 64 + lane;
+            nxt[e] = idx < m ? (FROM_TEXT ? init_record(T, m, idx, bits, ksym) : src[idx]) : 0ull;
+        }
+    }
     for (uint32_t t0 = 0; t0 < m; t0 += SORT_NT * SORT_E) {
         const uint32_t wbase = t0 + wave * (64 * SORT_E);
         uint64_t rec[SORT_E];
         uint32_t off[SORT_E], dig[SORT_E];
 #pragma unroll
-        for (int e = 0; e < SORT_E; e++) {
-            const uint32_t idx = wbase + e * 64 + lane;
-            rec[e] = idx < m ? (FROM_TEXT ? init_record(T, m, idx, bits, ksym) : src[idx]) : 0ull;
+        for (int e = 0; e < SORT_E; e++) rec[e] = nxt[e];
+        {
+            const uint32_t nbase = wbase + SORT_NT * SORT_E;
+#pragma unroll
+            for (int e = 0; e < SORT_E; e++) {
+                const uint32_t idx = nbase + e * 64 + lane;
+                nxt[e] = idx < m ? (FROM_TEXT ? init_record(T, m, idx, bits, ksym) : src[idx]) : 0ull;
+            }
         }
         uint32_t *wc = &s_wcnt[cur][wave * 256];
 #pragma unroll
@@ -155,7 +171,7 @@ __device__ void radix_pass(const uint64_t *__restrict__ src, uint64_t *__restric
             off[e] = old + rank;
             dig[e] = d;
         }
-        __syncthreads();
+        bzx_lds_barrier();
         if (tid < 256) {
             uint32_t run = s_base[tid];
 #pragma unroll
@@ -167,7 +183,7 @@ __device__ void radix_pass(const uint64_t *__restrict__ src, uint64_t *__restric
             s_base[tid] = run;
         }
         for (uint32_t i = tid; i < SORT_NW * 256; i += SORT_NT) s_wcnt[cur ^ 1][i] = 0;
-        __syncthreads();
+        bzx_lds_barrier();
 #pragma unroll
         for (int e = 0; e < SORT_E; e++) {
             const uint32_t idx = wbase + e * 64 + lane;

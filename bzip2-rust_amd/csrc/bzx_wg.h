@@ -5,6 +5,14 @@
 
 #define BZX_WAVE 64
 
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for outstanding
+// global loads/stores (vmcnt), so prefetched loads and scatter stores stay in flight across it.
+#ifdef BZX_HIP_EMU
+#define bzx_lds_barrier() __syncthreads()
+#else
+#define bzx_lds_barrier() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 __device__ __forceinline__ uint32_t bzx_lane() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t bzx_wave() { return threadIdx.x >> 6; }
 
