@@ -26,7 +26,7 @@ void bzx_launch_stream_frame(const BzxBatch &B, int level, const uint64_t *d_tot
 int bzx_split_launch_boundaries(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t max_blocks,
                                 BzxSplitWs *ws_out);
 void bzx_split_launch_scatter(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, const BzxSplitWs &ws,
-                              uint32_t nblk, uint8_t *d_slabs, BzxBlock *d_blk);
+                              uint32_t nblk, uint8_t *d_slabs, BzxBlock *d_blk, uint32_t own_first, uint32_t own_step);
 uint32_t bzx_bwt_max_blocks_per_cu();
 void bzx_launch_bits_export(const BzxBatch &B, long long *bits, hipStream_t stream);
 void bzx_launch_bits_import(const BzxBatch &B, const long long *bits, hipStream_t stream);
@@ -520,7 +520,8 @@ extern "C" int bzx_compress_block(bzx_ctx *ctx, const uint8_t *blk, size_t n, ui
 static int level_ok(int level) { return level >= 1 && level <= 9; }
 
 // Device split: raw (device) -> block slabs + descriptors (n, crc, in_off).  Returns the block count.
-static int split_on_device(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t *nblk_out)
+static int split_on_device(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t *nblk_out,
+                           uint32_t own_first = 0, uint32_t own_step = 1)
 {
     *nblk_out = 0;
     if (len == 0) return BZX_OK;
@@ -540,7 +541,7 @@ static int split_on_device(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int l
         ctx->err = "device block splitter produced an impossible block count";
         return BZX_E_HIP;
     }
-    bzx_split_launch_scatter(ctx, d_raw, len, ws, nblk, ctx->d_in, ctx->B.blk);
+    bzx_split_launch_scatter(ctx, d_raw, len, ws, nblk, ctx->d_in, ctx->B.blk, own_first, own_step);
     HIP_TRY(ctx, hipGetLastError());
     ctx->B.in = ctx->d_in;
     *nblk_out = nblk;
@@ -664,7 +665,7 @@ extern "C" int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, in
     uint32_t nblk = 0;
     ctx->B.blk_first = 0;
     ctx->B.blk_step = 1;
-    int rc = split_on_device(ctx, (const uint8_t *)d_raw, len, level, &nblk);
+    int rc = split_on_device(ctx, (const uint8_t *)d_raw, len, level, &nblk, rank, world);
     if (rc) return rc;
     if (nblk > bits_cap) return BZX_E_OUTBUF;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));

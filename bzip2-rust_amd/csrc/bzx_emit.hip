@@ -285,13 +285,16 @@ __global__ void bzx_bits_export_kernel(BzxBatch B, long long *bits)
 {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < B.nblk; j += gridDim.x * blockDim.x) {
         const uint32_t b = B.blk_first + j * B.blk_step;
-        bits[b] = (long long)B.blk[b].bits;
+        bits[b] = (long long)(B.blk[b].bits | ((uint64_t)B.blk[b].crc << 32));   // size (< 2^32 bits) and CRC of my block
     }
 }
 __global__ void bzx_bits_import_kernel(BzxBatch B, const long long *bits)
 {
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B.nblk; b += gridDim.x * blockDim.x)
-        B.blk[b].bits = (uint64_t)bits[b];
+    {
+        B.blk[b].bits = (uint64_t)bits[b] & 0xffffffffull;
+        B.blk[b].crc = (uint32_t)((uint64_t)bits[b] >> 32);
+    }
 }
 void bzx_launch_bits_export(const BzxBatch &B, long long *bits, hipStream_t stream)
 {

@@ -381,14 +381,29 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_boundaries_kernel(const uint8_t 
 }
 
 // ---- D: scatter the emitted bytes into the block slabs + fill the block descriptors' in_off / n
+// own_first/own_step: only blocks b = own_first (mod own_step) are materialised (round-robin sharding over GPUs).
 __global__ __launch_bounds__(RL_NT) void bzx_rl_scatter_kernel(const uint8_t *__restrict__ raw, uint64_t len,
                                                                uint64_t ntiles, BzxSplitWs ws, uint8_t *__restrict__ slabs,
-                                                               BzxBlock *__restrict__ blk)
+                                                               BzxBlock *__restrict__ blk, uint32_t own_first,
+                                                               uint32_t own_step)
 {
     __shared__ uint64_t s64[RL_NT / 64];
     __shared__ uint32_t s32[RL_NT / 64];
     const uint32_t nblk = ws.nblk[0];
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (own_step > 1) {
+            // skip tiles that lie entirely in blocks of other ranks (uniform decision)
+            const uint64_t pa = tile * RL_TILE;
+            const uint64_t pb = (pa + RL_TILE < len ? pa + RL_TILE : len) - 1;
+            uint32_t lo = 0, hi = nblk;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ws.blk_raw[mid] <= pa) lo = mid; else hi = mid;
+            }
+            const uint32_t ka = lo;
+            const uint32_t kb2 = (ka + 1 < nblk && ws.blk_raw[ka + 1] <= pb) ? ka + 1 : ka;
+            if ((ka % own_step) != own_first && (kb2 % own_step) != own_first) continue;
+        }
         TileInfo ti;
         tile_analyse(raw, len, tile, ws, s64, s32, ti);
         if (ti.t.nvalid) {
@@ -413,7 +428,9 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_scatter_kernel(const uint8_t *__
                         dst = slabs + (size_t)kb * BZX_BLK_STRIDE;
                     }
                     const uint32_t e = (uint32_t)(ti.e_bits >> (2 * i)) & 3u;
-                    if (e) {
+                    if (e && (kb % own_step) != own_first) {
+                        f += e;
+                    } else if (e) {
                         const uint32_t c = tile_byte(ti.t, i);
                         dst[f - f0] = (uint8_t)c;
                         if (e == 2) {
@@ -467,7 +484,8 @@ __device__ uint32_t gf_xpow8(uint64_t nbytes)
 
 #define CRC_NT 1024
 __global__ __launch_bounds__(CRC_NT) void bzx_rl_crc_kernel(const uint8_t *__restrict__ raw, BzxSplitWs ws,
-                                                            BzxBlock *__restrict__ blk)
+                                                            BzxBlock *__restrict__ blk, uint32_t own_first,
+                                                            uint32_t own_step)
 {
     // slicing-by-8 tables: tab[k][v] = register after byte v followed by k zero bytes (from a zero register)
     __shared__ uint32_t tab[8][256];
@@ -487,7 +505,7 @@ __global__ __launch_bounds__(CRC_NT) void bzx_rl_crc_kernel(const uint8_t *__res
         __syncthreads();
     }
     const uint32_t nblk = ws.nblk[0];
-    for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+    for (uint32_t b = own_first + blockIdx.x * own_step; b < nblk; b += gridDim.x * own_step) {
         const uint64_t lo = ws.blk_raw[b], hi = ws.blk_raw[b + 1];
         const uint64_t total = hi - lo;
         const uint64_t per = (total + CRC_NT - 1) / CRC_NT;
@@ -559,14 +577,15 @@ int bzx_split_launch_boundaries(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, 
 
 // Launches D and E for nblk blocks (ws.nblk on the device already holds nblk).
 void bzx_split_launch_scatter(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, const BzxSplitWs &ws, uint32_t nblk,
-                              uint8_t *d_slabs, BzxBlock *d_blk)
+                              uint8_t *d_slabs, BzxBlock *d_blk, uint32_t own_first, uint32_t own_step)
 {
     const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE;
     hipStream_t st = bzx_ctx_stream(ctx);
     const uint32_t grid = (uint32_t)(ntiles < (uint64_t)bzx_ctx_ncu(ctx) * 8 ? ntiles : (uint64_t)bzx_ctx_ncu(ctx) * 8);
-    hipLaunchKernelGGL(bzx_rl_scatter_kernel, dim3(grid), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, ws, d_slabs, d_blk);
-    const uint32_t cgrid = nblk < (uint32_t)bzx_ctx_ncu(ctx) * 2 ? nblk : (uint32_t)bzx_ctx_ncu(ctx) * 2;
-    hipLaunchKernelGGL(bzx_rl_crc_kernel, dim3(cgrid), dim3(CRC_NT), 0, st, d_raw, ws, d_blk);
+    hipLaunchKernelGGL(bzx_rl_scatter_kernel, dim3(grid), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, ws, d_slabs, d_blk, own_first, own_step);
+    const uint32_t mine = nblk > own_first ? (nblk - own_first + own_step - 1) / own_step : 0;
+    const uint32_t cgrid = mine < (uint32_t)bzx_ctx_ncu(ctx) * 2 ? (mine ? mine : 1) : (uint32_t)bzx_ctx_ncu(ctx) * 2;
+    hipLaunchKernelGGL(bzx_rl_crc_kernel, dim3(cgrid), dim3(CRC_NT), 0, st, d_raw, ws, d_blk, own_first, own_step);
 }
 
 uint32_t *bzx_split_nblk_ptr(const BzxSplitWs &ws) { return ws.nblk; }

@@ -124,3 +124,41 @@ def test_bad_arguments(bzx):
         bzx.compress_buffer(b"abc", 0)
     with pytest.raises(BzxError):
         bzx.compress_block(b"x" * 900001, 0)
+
+
+def test_periodic_blocks_stream(bzx, oracle):
+    """blocks that are u^k.  The last column is tie-invariant, origPtr must be libbz2's."""
+    for data, level in ((b"\0" * 600_000, 1),                 # RLE1 image (0,0,0,0,251)^k: periodic blocks
+                        (b"abcabcd" * 15, 9), (bytes(range(256)) * 40, 9), (b"\0\0\0\1" * 3000, 9)):
+        out = bzx.compress_buffer(data, level)
+        assert out == bz2.compress(data, level), (len(data), level)
+        assert bzx.stats().n_periodic >= 1
+
+
+def test_large_roundtrip_properties(bzx, oracle):
+    """Size-independent properties at a multi-hundred-block size (BASELINE configs[2] shape, scaled to keep the
+    test short): libbz2 decodes the device stream back to the input; block count and framing are right; the first
+    blocks are byte-identical to the oracle's stream of a prefix."""
+    n = 192 << 20
+    data = oracle.synthtext(n)
+    out = bzx.compress_buffer(data, 9)
+    st = bzx.stats()
+    assert out[:4] == b"BZh9" and st.nblk == (n + 899980) // 899981
+    assert bz2.decompress(out) == data
+    # prefix property: all blocks but the last of a prefix stream appear unchanged (bit-exact) at the start
+    pre = 8 * 899981 + 12345
+    ref, nb = oracle.compress(data[:pre], 9)
+    assert nb == 9
+    # the first 8 blocks end on a bit boundary; compare whole bytes safely inside them
+    assert out[: len(ref) - 300_000] == ref[: len(ref) - 300_000]
+
+
+def test_random_and_zero_heavy_inputs(bzx, oracle):
+    """BASELINE configs[4] shapes at reduced size: incompressible bytes (sort worst case for MTF) and an
+    all-zero input (RLE1-heavy, periodic blocks)."""
+    rnd = oracle.randbytes(24 << 20)
+    out = bzx.compress_buffer(rnd, 9)
+    assert out == bz2.compress(rnd, 9)
+    z = b"\0" * (48 << 20)          # 1 periodic block of 899,985 bytes + tail
+    out = bzx.compress_buffer(z, 9)
+    assert out == bz2.compress(z, 9)
