@@ -128,7 +128,7 @@ def test_bad_arguments(bzx):
 
 def test_periodic_blocks_stream(bzx, oracle):
     """blocks that are u^k.  The last column is tie-invariant, origPtr must be libbz2's."""
-    for data, level in ((b"\0" * 600_000, 1),                 # RLE1 image (0,0,0,0,251)^k: periodic blocks
+    for data, level in ((b"\0" * 6_000_000, 1),               # RLE1 image (0,0,0,0,251)^k: periodic blocks
                         (b"abcabcd" * 15, 9), (bytes(range(256)) * 40, 9), (b"\0\0\0\1" * 3000, 9)):
         out = bzx.compress_buffer(data, level)
         assert out == bz2.compress(data, level), (len(data), level)
