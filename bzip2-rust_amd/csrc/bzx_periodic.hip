@@ -149,79 +149,6 @@ __device__ static void fb_qsort3(uint32_t *fmap, const uint32_t *eclass, int32_t
 #define WORD_BH(z) bhtab[(z) >> 5]
 #define UNALIGNED_BH(z) ((z) & 0x1f)
 
-/* fmap: out, n entries.  eclass: scratch, n entries.  bhtab: scratch, 2 + n/32 + 2 words... */
-__device__ static void fallback_sort(const uint8_t *block, uint32_t *fmap, uint32_t *eclass, uint32_t *bhtab,
-                          int32_t nblock)
-{
-    int32_t ftab[257];
-    int32_t H, i, j, k, l, r, cc, cc1, n_not_done, n_bhtab;
-
-    for (i = 0; i < 257; i++) ftab[i] = 0;
-    for (i = 0; i < nblock; i++) ftab[block[i]]++;
-    for (i = 1; i < 257; i++) ftab[i] += ftab[i - 1];
-    for (i = 0; i < nblock; i++) {
-        j = block[i];
-        k = ftab[j] - 1;
-        ftab[j] = k;
-        fmap[k] = (uint32_t)i;
-    }
-
-    n_bhtab = 2 + (nblock / 32);
-    for (i = 0; i < n_bhtab; i++) bhtab[i] = 0;
-    for (i = 0; i < 256; i++) SET_BH(ftab[i]);
-
-    for (i = 0; i < 32; i++) {
-        SET_BH(nblock + 2 * i);
-        CLEAR_BH(nblock + 2 * i + 1);
-    }
-
-    H = 1;
-    for (;;) {
-        j = 0;
-        for (i = 0; i < nblock; i++) {
-            if (ISSET_BH(i)) j = i;
-            k = (int32_t)fmap[i] - H;
-            if (k < 0) k += nblock;
-            eclass[k] = (uint32_t)j;
-        }
-
-        n_not_done = 0;
-        r = -1;
-        for (;;) {
-            k = r + 1;
-            while (ISSET_BH(k) && UNALIGNED_BH(k)) k++;
-            if (ISSET_BH(k)) {
-                while (WORD_BH(k) == 0xffffffffu) k += 32;
-                while (ISSET_BH(k)) k++;
-            }
-            l = k - 1;
-            if (l >= nblock) break;
-            while (!ISSET_BH(k) && UNALIGNED_BH(k)) k++;
-            if (!ISSET_BH(k)) {
-                while (WORD_BH(k) == 0x00000000u) k += 32;
-                while (!ISSET_BH(k)) k++;
-            }
-            r = k - 1;
-            if (r >= nblock) break;
-
-            if (r > l) {
-                n_not_done += (r - l + 1);
-                fb_qsort3(fmap, eclass, l, r);
-                cc = -1;
-                for (i = l; i <= r; i++) {
-                    cc1 = (int32_t)eclass[fmap[i]];
-                    if (cc != cc1) {
-                        SET_BH(i);
-                        cc = cc1;
-                    }
-                }
-            }
-        }
-        H *= 2;
-        if (H > nblock || n_not_done == 0) break;
-    }
-}
-
 /* ------------------------------------------------------------------ main sort */
 
 // Work-budget shortcut (exact): while no quadrant descriptor has been written yet (every quadrant is 0) two
@@ -519,49 +446,201 @@ __device__ static void main_sort(uint32_t *ptr, uint8_t *block, uint16_t *quadra
 }
 
 
-// Workspace layout inside a sort slot (BzxSortWs): ptr = sa[], eclass = isa[], block copy + quadrant in u0,
-// ftab / bhtab in u1.
-__global__ __launch_bounds__(64) void bzx_periodic_kernel(BzxBatch B)
+// ---- cooperative form of the fallback sort ---------------------------------------------------------------
+// Same algorithm and, step for step, the same permutation as fallback_sort above (libbz2 fallbackSort), run by a
+// whole workgroup: the position-parallel parts (bucket fill, equivalence-class assignment, header bits) are
+// spread over the lanes, lane 0 walks the buckets and runs the 3-way quicksort, and large buckets whose keys
+// are all equal -- the common case in a periodic block once the doubling depth passes the period; libbz2's
+// quicksort provably leaves such a bucket untouched -- are recognised in parallel and skipped.
+#define PER_NT 256
+#define PER_COOP_MIN 4096
+
+__device__ static void fallback_sort_coop(const uint8_t *__restrict__ T, uint32_t *fmap, uint32_t *eclass,
+                                          uint32_t *bhtab, uint32_t *cnt /* [PER_NT][256] */, int32_t nblock)
 {
+    __shared__ int32_t s_start[257];
+    __shared__ uint32_t s_scan[PER_NT];
+    __shared__ int32_t s_cmd[4];       // [0] 1 = big bucket, 0 = round finished; [1] l; [2] r; [3] n_not_done
+    const uint32_t tid = threadIdx.x;
+    const int32_t chunk = (nblock + PER_NT - 1) / PER_NT;
+    const int32_t ca = (int32_t)tid * chunk < nblock ? (int32_t)tid * chunk : nblock;
+    const int32_t cb = ca + chunk < nblock ? ca + chunk : nblock;
+
+    // ---- initial bucket sort by first byte; within a bucket the rotation indices are DESCENDING, as libbz2 leaves them
+    for (int32_t c = 0; c < 256; c++) cnt[tid * 256 + c] = 0;
+    for (int32_t i = ca; i < cb; i++) cnt[tid * 256 + T[i]]++;
+    __syncthreads();
+    {
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < PER_NT; t++) {
+            const uint32_t v = cnt[t * 256 + tid];
+            cnt[t * 256 + tid] = run;
+            run += v;
+        }
+        s_scan[tid] = run;      // occurrences of byte value tid
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int32_t acc = 0;
+        for (int32_t c = 0; c < 256; c++) {
+            s_start[c] = acc;
+            acc += (int32_t)s_scan[c];
+        }
+        s_start[256] = acc;
+    }
+    __syncthreads();
+    for (int32_t i = ca; i < cb; i++) {
+        const uint32_t c = T[i];
+        const uint32_t rnk = cnt[tid * 256 + c]++;        // number of earlier positions holding c
+        fmap[s_start[c + 1] - 1 - (int32_t)rnk] = (uint32_t)i;
+    }
+    const int32_t n_bh = nblock / 32 + 8;
+    for (int32_t i = (int32_t)tid; i < n_bh; i += PER_NT) bhtab[i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        for (int32_t c = 0; c < 256; c++) SET_BH(s_start[c]);
+        for (int32_t i = 0; i < 32; i++) {
+            SET_BH(nblock + 2 * i);
+            CLEAR_BH(nblock + 2 * i + 1);
+        }
+    }
+    __syncthreads();
+
+    int32_t H = 1;
+    // lane 0's bucket walk state
+    int32_t k = 0, l = 0, r = -1, n_not_done = 0;
+    for (;;) {
+        // ---- equivalence classes: eclass[fmap[i] - H] = position of the bucket header at or before i
+        {
+            uint32_t last = 0;      // 1 + last header position inside my chunk
+            for (int32_t i = ca; i < cb; i++)
+                if (ISSET_BH(i)) last = (uint32_t)i + 1;
+            s_scan[tid] = last;
+            __syncthreads();
+            uint32_t jin = 0;
+            for (uint32_t t = 0; t < tid; t++)
+                if (s_scan[t] > jin) jin = s_scan[t];
+            int32_t j = jin ? (int32_t)jin - 1 : 0;
+            for (int32_t i = ca; i < cb; i++) {
+                if (ISSET_BH(i)) j = i;
+                int32_t kk = (int32_t)fmap[i] - H;
+                if (kk < 0) kk += nblock;
+                eclass[kk] = (uint32_t)j;
+            }
+        }
+        __syncthreads();
+
+        // ---- buckets: lane 0 enumerates them exactly as libbz2 does; big ones are handled by everybody
+        if (tid == 0) {
+            n_not_done = 0;
+            r = -1;
+        }
+        for (;;) {
+            if (tid == 0) {
+                s_cmd[0] = 0;
+                for (;;) {
+                    k = r + 1;
+                    while (ISSET_BH(k) && UNALIGNED_BH(k)) k++;
+                    if (ISSET_BH(k)) {
+                        while (WORD_BH(k) == 0xffffffffu) k += 32;
+                        while (ISSET_BH(k)) k++;
+                    }
+                    l = k - 1;
+                    if (l >= nblock) break;
+                    while (!ISSET_BH(k) && UNALIGNED_BH(k)) k++;
+                    if (!ISSET_BH(k)) {
+                        while (WORD_BH(k) == 0x00000000u) k += 32;
+                        while (!ISSET_BH(k)) k++;
+                    }
+                    r = k - 1;
+                    if (r >= nblock) break;
+                    if (r > l) {
+                        n_not_done += (r - l + 1);
+                        if (r - l + 1 >= PER_COOP_MIN) {
+                            s_cmd[0] = 1;
+                            s_cmd[1] = l;
+                            s_cmd[2] = r;
+                            break;
+                        }
+                        fb_qsort3(fmap, eclass, l, r);
+                        int32_t cc = -1;
+                        for (int32_t i = l; i <= r; i++) {
+                            const int32_t cc1 = (int32_t)eclass[fmap[i]];
+                            if (cc != cc1) {
+                                SET_BH(i);
+                                cc = cc1;
+                            }
+                        }
+                    }
+                }
+                s_cmd[3] = n_not_done;
+            }
+            __syncthreads();
+            if (s_cmd[0] == 0) break;
+            const int32_t bl = s_cmd[1], br = s_cmd[2];
+            const uint32_t key0 = eclass[fmap[bl]];
+            int same = 1;
+            for (int32_t i = bl + (int32_t)tid; i <= br; i += PER_NT)
+                if (eclass[fmap[i]] != key0) same = 0;
+            const int all_same = __syncthreads_and(same);
+            if (!all_same) {
+                if (tid == 0) fb_qsort3(fmap, eclass, bl, br);
+                __syncthreads();
+                for (int32_t i = bl + 1 + (int32_t)tid; i <= br; i += PER_NT)
+                    if (eclass[fmap[i]] != eclass[fmap[i - 1]]) atomicOr(&bhtab[i >> 5], (uint32_t)1 << (i & 31));
+            }
+            __syncthreads();
+        }
+        const int32_t nnd = s_cmd[3];
+        __syncthreads();
+        H *= 2;
+        if (H > nblock || nnd == 0) break;
+    }
+}
+
+// Workspace layout inside a sort slot (BzxSortWs): ptr = sa[], eclass = isa[], block copy + quadrant in u0,
+// ftab / bhtab / per-lane byte counts in u1.
+__global__ __launch_bounds__(PER_NT) void bzx_periodic_kernel(BzxBatch B)
+{
+    __shared__ int s_need_fallback;
     const BzxSortWs ws = B.sort_ws[blockIdx.x];
     const uint32_t n_per = B.counters[5];
     for (uint32_t li = blockIdx.x; li < n_per; li += gridDim.x) {
         const uint32_t b = B.plist[li];
-        if (threadIdx.x == 0) {
-            const int32_t n = (int32_t)B.blk[b].n;
-            const uint8_t *T = B.in + B.blk[b].in_off;
-            uint32_t *ptr = ws.sa;
-            uint32_t *eclass = ws.isa;
-            uint8_t *block = (uint8_t *)ws.u0;                                  // n + N_OVERSHOOT bytes
-            uint16_t *quadrant = (uint16_t *)(block + ((n + N_OVERSHOOT + 15) & ~15));   // n + N_OVERSHOOT entries
-            uint32_t *ftab = (uint32_t *)ws.u1;                                 // 65537 words
-            uint32_t *bhtab = ftab + 65600;                                     // n/32 + 8 words
-            bool need_fallback = true;
-            if (n >= 10000) {
-                for (int32_t i = 0; i < n; i++) block[i] = T[i];
+        const int32_t n = (int32_t)B.blk[b].n;
+        const uint8_t *T = B.in + B.blk[b].in_off;
+        uint32_t *ptr = ws.sa;
+        uint32_t *eclass = ws.isa;
+        uint8_t *block = (uint8_t *)ws.u0;                                  // n + N_OVERSHOOT bytes
+        uint16_t *quadrant = (uint16_t *)(block + ((n + N_OVERSHOOT + 15) & ~15));   // n + N_OVERSHOOT entries
+        uint32_t *ftab = (uint32_t *)ws.u1;                                 // 65537 words
+        uint32_t *bhtab = ftab + 65600;                                     // n/32 + 8 words
+        uint32_t *cnt = bhtab + 32768;                                      // PER_NT * 256 words
+        if (threadIdx.x == 0) s_need_fallback = 1;
+        __syncthreads();
+        if (n >= 10000) {
+            for (int32_t i = (int32_t)threadIdx.x; i < n; i += PER_NT) block[i] = T[i];
+            __syncthreads();
+            if (threadIdx.x == 0) {
                 int32_t budget = n * ((30 - 1) / 3);
                 PeriodInfo pinfo;
                 const uint32_t copies = B.blk[b].pad_[0];
                 pinfo.period = (copies > 1 && (uint32_t)n % copies == 0) ? (uint32_t)n / copies : (uint32_t)n;
                 pinfo.quadrant_clean = 1;
                 main_sort(ptr, block, quadrant, ftab, n, &budget, &pinfo);
-                need_fallback = budget < 0;
+                s_need_fallback = budget < 0;
             }
-            if (need_fallback) {
-                for (int32_t i = 0; i < n / 32 + 8; i++) bhtab[i] = 0;
-                fallback_sort(T, ptr, eclass, bhtab, n);
-            }
-            for (int32_t i = 0; i < n; i++)
-                if (ptr[i] == 0) {
-                    B.blk[b].orig_ptr = (uint32_t)i;
-                    break;
-                }
+            __syncthreads();
         }
+        if (s_need_fallback) fallback_sort_coop(T, ptr, eclass, bhtab, cnt, n);
+        __syncthreads();
+        for (int32_t i = (int32_t)threadIdx.x; i < n; i += PER_NT)
+            if (ptr[i] == 0) B.blk[b].orig_ptr = (uint32_t)i;
         __syncthreads();
     }
 }
 
 void bzx_launch_periodic(const BzxBatch &B, uint32_t grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL(bzx_periodic_kernel, dim3(grid), dim3(64), 0, stream, B);
+    hipLaunchKernelGGL(bzx_periodic_kernel, dim3(grid), dim3(PER_NT), 0, stream, B);
 }

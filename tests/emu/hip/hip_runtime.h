@@ -193,3 +193,13 @@ inline int __syncthreads_or(int p)
     __syncthreads();
     return acc;
 }
+inline int __syncthreads_and(int p)
+{
+    static int acc;
+    __syncthreads();
+    if (threadIdx.x == 0) acc = 1;
+    __syncthreads();
+    if (!p) acc = 0;
+    __syncthreads();
+    return acc;
+}
