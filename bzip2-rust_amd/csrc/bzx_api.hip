@@ -544,6 +544,7 @@ static int split_on_device(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int l
     bzx_split_launch_scatter(ctx, d_raw, len, ws, nblk, ctx->d_in, ctx->B.blk, own_first, own_step);
     HIP_TRY(ctx, hipGetLastError());
     ctx->B.in = ctx->d_in;
+    ctx->B.raw = d_raw;
     *nblk_out = nblk;
     return BZX_OK;
 }
@@ -642,8 +643,9 @@ extern "C" int bzx_split_rle1(bzx_ctx *ctx, const uint8_t *raw, size_t len, int 
             rc = BZX_E_HIP;
             break;
         }
-        if (hipMemcpy(blocks_out + (size_t)b * BZX_MAX_BLOCK, ctx->d_in + (size_t)b * BZX_BLK_STRIDE, ns[b],
-                      hipMemcpyDeviceToHost) != hipSuccess)
+        const uint64_t off = ctx->h_blk[b].in_off;
+        const uint8_t *src = (off & BZX_IN_RAW) ? (const uint8_t *)d_raw + (off & ~BZX_IN_RAW) : ctx->d_in + off;
+        if (hipMemcpy(blocks_out + (size_t)b * BZX_MAX_BLOCK, src, ns[b], hipMemcpyDeviceToHost) != hipSuccess)
             rc = BZX_E_HIP;
     }
     (void)hipStreamSynchronize(ctx->stream);

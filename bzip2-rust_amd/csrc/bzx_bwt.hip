@@ -539,7 +539,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         const uint32_t b = B.blk_first + j_ * B.blk_step;
 
         const uint32_t n = B.blk[b].n;
-        const uint8_t *__restrict__ T = B.in + B.blk[b].in_off;
+        const uint8_t *__restrict__ T = BZX_BLOCK_PTR(B, B.blk[b]);
         uint8_t *__restrict__ L = B.bwt + (size_t)b * BZX_BLK_STRIDE;
         if (B.dbg && tid == 0) t_last = wall_clock64();
 

@@ -17,12 +17,14 @@
 #define BZX_MAX_SEL 18002          // ceil(900001 / 50)
 #define BZX_SEL_STRIDE 18048
 
+#define BZX_IN_RAW (1ull << 63)
 #define BZX_ST_PERIODIC 1u         // block is u^k, k>1: identical rotations exist
 
 // Per-block descriptor, device resident; filled by the splitter (or the host for the
 // per-block entry points), completed by each stage.
 struct BzxBlock {
-    uint64_t in_off;        // byte offset of the RLE1'd block in the block slab buffer
+    uint64_t in_off;        // byte offset of the RLE1'd block in the block slab buffer (BzxBatch.in); with
+                            // BZX_IN_RAW set: offset into the raw input (BzxBatch.raw) -- RLE1 is the identity there
     uint32_t n;             // RLE1'd length (1..BZX_MAX_N)
     uint32_t crc;           // CRC-32/BZIP2 of the raw bytes the block covers
     uint32_t orig_ptr;      // BWT: row of rotation 0
@@ -56,6 +58,7 @@ struct BzxBatch {
     uint32_t *counters;     // [64] atomic work counters, one per stage kernel (zeroed per batch); [5] = #periodic
     uint32_t *plist;        // [nblk] indices of the blocks flagged periodic by the BWT kernel
     const uint8_t *in;      // block slab buffer (RLE1'd bytes), block b at blk[b].in_off
+    const uint8_t *raw;     // raw input (blocks on which RLE1 is the identity are read in place)
     uint8_t *bwt;           // [nblk][BZX_BLK_STRIDE]  last column L
     uint8_t *rank;          // [nblk][BZX_BLK_STRIDE]  MTF rank of every L byte
     uint16_t *mtfv;         // [nblk][BZX_BLK_STRIDE]  symbols (RUNA/RUNB/rank+1/EOB)
@@ -83,7 +86,11 @@ struct BzxSplitWs {
     uint64_t *tile_np;     // [ntiles+1] B: 1 if the tile has a run position with k >= 3 / after S3: prefix count
     uint64_t *blk_raw;     // [max_blocks+1] raw start of every block; [nblk] = len
     uint64_t *blk_f;       // [max_blocks+1] F at the block start
+    uint32_t *blk_plain;   // [max_blocks+1] 1 = RLE1 is the identity on the whole block (zero-copy)
     uint32_t *nblk;        // [1]
     uint32_t max_blocks;
 };
 
+
+// Block bytes of a descriptor.
+#define BZX_BLOCK_PTR(B, d) (((d).in_off & BZX_IN_RAW) ? ((B).raw + ((d).in_off & ~BZX_IN_RAW)) : ((B).in + (d).in_off))

@@ -608,7 +608,7 @@ __global__ __launch_bounds__(PER_NT) void bzx_periodic_kernel(BzxBatch B)
     for (uint32_t li = blockIdx.x; li < n_per; li += gridDim.x) {
         const uint32_t b = B.plist[li];
         const int32_t n = (int32_t)B.blk[b].n;
-        const uint8_t *T = B.in + B.blk[b].in_off;
+        const uint8_t *T = BZX_BLOCK_PTR(B, B.blk[b]);
         uint32_t *ptr = ws.sa;
         uint32_t *eclass = ws.isa;
         uint8_t *block = (uint8_t *)ws.u0;                                  // n + N_OVERSHOOT bytes

@@ -257,10 +257,13 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_boundaries_kernel(const uint8_t 
         if (tid == 0) {
             ws.blk_raw[nb] = start;
             ws.blk_f[nb] = f_start;
+            ws.blk_plain[nb] = 0;
         }
         nb++;
         const uint64_t target = f_start + nmax;
         if (f_len < target) {
+            // last block: plain if no tile from here to the end has a run position k >= 3
+            if (tid == 0 && ws.tile_np[ntiles] == ws.tile_np[start / RL_TILE]) ws.blk_plain[nb - 1] = 1;
             start = len;
             f_start = f_len;
             break;
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_boundaries_kernel(const uint8_t 
                         kk++;
                     }
                 }
+                if (tid == 0) ws.blk_plain[nb - 1] = 1;
                 start = q;
                 f_start = f_start + (q - (x - nmax));
                 continue;
@@ -391,8 +395,8 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_scatter_kernel(const uint8_t *__
     __shared__ uint32_t s32[RL_NT / 64];
     const uint32_t nblk = ws.nblk[0];
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (own_step > 1) {
-            // skip tiles that lie entirely in blocks of other ranks (uniform decision)
+        {
+            // skip tiles that lie entirely in blocks of other ranks or in zero-copy blocks (uniform decision)
             const uint64_t pa = tile * RL_TILE;
             const uint64_t pb = (pa + RL_TILE < len ? pa + RL_TILE : len) - 1;
             uint32_t lo = 0, hi = nblk;
@@ -402,7 +406,9 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_scatter_kernel(const uint8_t *__
             }
             const uint32_t ka = lo;
             const uint32_t kb2 = (ka + 1 < nblk && ws.blk_raw[ka + 1] <= pb) ? ka + 1 : ka;
-            if ((ka % own_step) != own_first && (kb2 % own_step) != own_first) continue;
+            const bool need_a = (ka % own_step) == own_first && !ws.blk_plain[ka];
+            const bool need_b = (kb2 % own_step) == own_first && !ws.blk_plain[kb2];
+            if (!need_a && !need_b) continue;
         }
         TileInfo ti;
         tile_analyse(raw, len, tile, ws, s64, s32, ti);
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_scatter_kernel(const uint8_t *__
                         dst = slabs + (size_t)kb * BZX_BLK_STRIDE;
                     }
                     const uint32_t e = (uint32_t)(ti.e_bits >> (2 * i)) & 3u;
-                    if (e && (kb % own_step) != own_first) {
+                    if (e && ((kb % own_step) != own_first || ws.blk_plain[kb])) {
                         f += e;
                     } else if (e) {
                         const uint32_t c = tile_byte(ti.t, i);
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_scatter_kernel(const uint8_t *__
         __syncthreads();
     }
     for (uint32_t b = blockIdx.x * RL_NT + threadIdx.x; b < nblk; b += gridDim.x * RL_NT) {
-        blk[b].in_off = (uint64_t)b * BZX_BLK_STRIDE;
+        blk[b].in_off = ws.blk_plain[b] ? (BZX_IN_RAW | ws.blk_raw[b]) : (uint64_t)b * BZX_BLK_STRIDE;
         blk[b].n = (uint32_t)(ws.blk_f[b + 1] - ws.blk_f[b]);
         blk[b].status = 0;
     }
@@ -550,7 +556,7 @@ int bzx_split_launch_boundaries(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, 
                                 BzxSplitWs *ws_out)
 {
     const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE;
-    const size_t bytes = (3 * (ntiles + 2) + 2 * ((size_t)max_blocks + 2)) * sizeof(uint64_t) + 64;
+    const size_t bytes = (3 * (ntiles + 2) + 3 * ((size_t)max_blocks + 2)) * sizeof(uint64_t) + 64;
     void *p = nullptr;
     int rc = bzx_ctx_split_scratch(ctx, bytes, &p);
     if (rc) return rc;
@@ -560,7 +566,8 @@ int bzx_split_launch_boundaries(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, 
     ws.tile_np = ws.tile_off + (ntiles + 2);
     ws.blk_raw = ws.tile_np + (ntiles + 2);
     ws.blk_f = ws.blk_raw + (max_blocks + 2);
-    ws.nblk = (uint32_t *)(ws.blk_f + (max_blocks + 2));
+    ws.blk_plain = (uint32_t *)(ws.blk_f + (max_blocks + 2));
+    ws.nblk = (uint32_t *)((uint64_t *)ws.blk_plain + (max_blocks + 2));
     ws.max_blocks = max_blocks;
     hipStream_t st = bzx_ctx_stream(ctx);
     const uint32_t grid = (uint32_t)(ntiles < (uint64_t)bzx_ctx_ncu(ctx) * 8 ? ntiles : (uint64_t)bzx_ctx_ncu(ctx) * 8);
