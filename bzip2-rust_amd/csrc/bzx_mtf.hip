@@ -46,6 +46,63 @@ struct Seen256 {
     }
 };
 
+// MTF ranks of my chunk with the WHOLE list in registers (alphabets of <= 8*NWORD symbols, e.g. text):
+// byte k of word k/8 = list entry k.  Branch-free: every lane finds the word and byte that hold the symbol
+// with the zero-byte trick, then every word is either shifted by one entry (words before the hit), patched
+// (the hit word) or left alone -- no LDS traffic and no divergence inside the loop.
+template <int NWORD>
+__device__ __forceinline__ void mtf_ranks_regs(const uint8_t *__restrict__ L, uint8_t *__restrict__ R, uint32_t c_lo,
+                                               uint32_t c_hi, const uint64_t *lst64, const uint8_t *seq)
+{
+    const uint64_t ones = 0x0101010101010101ull, highs = 0x8080808080808080ull;
+    uint64_t w[NWORD];
+#pragma unroll
+    for (int i = 0; i < NWORD; i++) w[i] = lst64[i];
+    for (uint32_t i0 = c_lo; i0 < c_hi; i0 += 16) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(L + i0);
+        const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+        uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = i0 + q * 4 + k;
+                if (i < c_hi) {
+                    const uint64_t s = seq[(wd[q] >> (8 * k)) & 255u];
+                    const uint64_t sp = s * ones;
+                    // hit word h and byte j
+                    uint32_t h = NWORD, j = 0;
+#pragma unroll
+                    for (int t = NWORD - 1; t >= 0; t--) {
+                        const uint64_t x = w[t] ^ sp;
+                        const uint64_t z = (x - ones) & ~x & highs;
+                        if (z) {
+                            h = (uint32_t)t;
+                            j = (uint32_t)(__ffsll((unsigned long long)z) - 1) >> 3;
+                        }
+                    }
+                    const uint32_t rank = 8 * h + j;
+                    if (rank) {
+                        const uint64_t lowmask = j ? ((1ull << (8 * j)) - 1ull) : 0ull;
+                        const uint64_t himask = j == 7 ? 0ull : (~0ull << (8 * (j + 1)));
+                        uint64_t carry = s;
+#pragma unroll
+                        for (int t = 0; t < NWORD; t++) {
+                            const uint64_t cur = w[t];
+                            const uint64_t shifted = (cur << 8) | carry;
+                            const uint64_t patched = (cur & himask) | ((cur & lowmask) << 8) | carry;
+                            w[t] = (uint32_t)t < h ? shifted : ((uint32_t)t == h ? patched : cur);
+                            carry = cur >> 56;
+                        }
+                    }
+                    o[q] |= rank << (8 * k);
+                }
+            }
+        }
+        *reinterpret_cast<uint4 *>(R + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 #define MTF_STAMP(slot)                                                       \
     do {                                                                      \
         if (B.dbg && tid == 0) {                                              \
@@ -170,7 +227,13 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         // ---- 5. plain MTF over my chunk (rle2_mtf.rs:61-138), rank bytes to HBM.
         // The first 8 list entries live in a register (byte 0 = front); deeper entries in LDS as 8-byte words,
         // searched and shifted one word at a time.
-        if (have_chunk) {
+        if (have_chunk && n_in_use <= 32) {
+            const uint64_t *lst64 = reinterpret_cast<const uint64_t *>(m_list + tid * stride);
+            if (n_in_use <= 8) mtf_ranks_regs<1>(L, R, c_lo, c_hi, lst64, m_seq);
+            else if (n_in_use <= 16) mtf_ranks_regs<2>(L, R, c_lo, c_hi, lst64, m_seq);
+            else if (n_in_use <= 24) mtf_ranks_regs<3>(L, R, c_lo, c_hi, lst64, m_seq);
+            else mtf_ranks_regs<4>(L, R, c_lo, c_hi, lst64, m_seq);
+        } else if (have_chunk) {
             uint64_t *lst64 = reinterpret_cast<uint64_t *>(m_list + tid * stride);
             uint64_t w = lst64[0];
             const uint64_t ones = 0x0101010101010101ull, highs = 0x8080808080808080ull;
