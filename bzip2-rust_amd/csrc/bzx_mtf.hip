@@ -14,13 +14,16 @@
 #include "bzx_device.h"
 #include "bzx_wg.h"
 
-#define MTF_NT 512
+#define MTF_NT 1024
 #define MTF_LIST_BYTES (72 * 1024)
 #define MTF_E 16
 
 __shared__ __attribute__((aligned(16))) uint8_t m_rec[MTF_LIST_BYTES];    // per-chunk recency lists (most recent first)
 __shared__ __attribute__((aligned(16))) uint8_t m_list[MTF_LIST_BYTES];   // per-chunk working MTF lists
 __shared__ uint16_t m_reccnt[MTF_NT];
+#define MTF_GROUP 32                                   // chunks per group of the two-level start-list walk
+__shared__ uint8_t m_super[(MTF_NT / MTF_GROUP) * 264];   // recency list of every group of 32 chunks
+__shared__ uint16_t m_supercnt[MTF_NT / MTF_GROUP];
 __shared__ uint32_t m_inuse[256];
 __shared__ uint8_t m_seq[256];
 __shared__ uint32_t m_freq[BZX_MAX_ALPHA + 2];
@@ -201,18 +204,48 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         __syncthreads();
         MTF_STAMP(33);
 
-        // ---- 4. MTF list at my chunk start: walk the earlier chunks backwards
-        if (have_chunk) {
+        // ---- 4a. recency list of every group of 32 chunks (one lane per group)
+        if (tid * MTF_GROUP < nch_used) {
             Seen256 seen;
             seen.clear();
             uint32_t cnt = 0;
-            uint8_t *lst = m_list + tid * stride;
-            for (uint32_t c = tid; c > 0 && cnt < n_in_use;) {
+            uint8_t *sup = m_super + tid * 264;
+            const uint32_t g_lo = tid * MTF_GROUP;
+            const uint32_t g_hi = g_lo + MTF_GROUP < nch_used ? g_lo + MTF_GROUP : nch_used;
+            for (uint32_t c = g_hi; c > g_lo && cnt < n_in_use;) {
                 c--;
                 const uint8_t *rec = m_rec + c * stride;
                 const uint32_t rc = m_reccnt[c];
                 for (uint32_t k = 0; k < rc; k++) {
                     const uint32_t s = rec[k];
+                    if (!seen.test_set(s)) sup[cnt++] = (uint8_t)s;
+                }
+            }
+            m_supercnt[tid] = (uint16_t)cnt;
+        }
+        __syncthreads();
+        // ---- 4b. MTF list at my chunk start: earlier chunks of my group, then earlier groups, most recent first
+        if (have_chunk) {
+            Seen256 seen;
+            seen.clear();
+            uint32_t cnt = 0;
+            uint8_t *lst = m_list + tid * stride;
+            const uint32_t g = tid / MTF_GROUP;
+            for (uint32_t c = tid; c > g * MTF_GROUP && cnt < n_in_use;) {
+                c--;
+                const uint8_t *rec = m_rec + c * stride;
+                const uint32_t rc = m_reccnt[c];
+                for (uint32_t k = 0; k < rc; k++) {
+                    const uint32_t s = rec[k];
+                    if (!seen.test_set(s)) lst[cnt++] = (uint8_t)s;
+                }
+            }
+            for (uint32_t gg = g; gg > 0 && cnt < n_in_use;) {
+                gg--;
+                const uint8_t *sup = m_super + gg * 264;
+                const uint32_t rc = m_supercnt[gg];
+                for (uint32_t k = 0; k < rc; k++) {
+                    const uint32_t s = sup[k];
                     if (!seen.test_set(s)) lst[cnt++] = (uint8_t)s;
                 }
             }
@@ -296,6 +329,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
             m_bcast[2] = 0;
         }
         __syncthreads();
+        uint32_t hot0 = 0, hot1 = 0, hot2 = 0;      // RUNA, RUNB and symbol 2 (rank 1) counted in registers
         for (uint32_t t0 = 0; t0 < n; t0 += MTF_NT * MTF_E) {
             const uint32_t i0 = t0 + tid * MTF_E;
             const uint32_t carry_p1 = m_bcast[1], carry_out = m_bcast[2];
@@ -343,13 +377,13 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
                         for (;;) {
                             const uint32_t sym = zr & 1u;
                             V[o++] = (uint16_t)sym;
-                            atomicAdd(&m_freq[sym], 1u);
+                            if (sym) hot1++; else hot0++;
                             if (zr < 2) break;
                             zr = (zr - 2) >> 1;
                         }
                     }
                     V[o++] = (uint16_t)(r + 1);
-                    atomicAdd(&m_freq[r + 1], 1u);
+                    if (r == 1) hot2++; else atomicAdd(&m_freq[r + 1], 1u);
                     p1 = i + 1;
                 }
             }
@@ -359,6 +393,10 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
             }
             __syncthreads();
         }
+        if (hot0) atomicAdd(&m_freq[0], hot0);
+        if (hot1) atomicAdd(&m_freq[1], hot1);
+        if (hot2) atomicAdd(&m_freq[2], hot2);
+        __syncthreads();
         MTF_STAMP(36);
         // trailing zero run + EOB
         if (tid == 0) {
