@@ -114,7 +114,7 @@ __device__ __forceinline__ uint64_t init_record(const uint8_t *__restrict__ T, u
 // One stable LSD pass: src[0..m) -> dst by the 8-bit digit at `shift`; hist = digit histogram (LDS).
 // FROM_TEXT: the source records are generated on the fly from the block bytes (first pass of the initial sort).
 template <bool FROM_TEXT>
-__device__ void radix_pass(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint32_t m, int shift,
+__device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint32_t m, int shift,
                            const uint32_t *hist, const uint8_t *__restrict__ T = nullptr, uint32_t bits = 8,
                            uint32_t ksym = 4)
 {
@@ -199,7 +199,7 @@ __device__ void radix_pass(const uint64_t *__restrict__ src, uint64_t *__restric
 // in RANK mode ISA[sa] = rank.  Members of groups of size > 1 are compacted to Unew/Snew (slot = SA position).
 // Returns the number of unresolved rotations; s_bcast[3] = size of the largest group.
 template <int MODE>
-__device__ uint32_t rerank(const uint64_t *__restrict__ U, const uint32_t *__restrict__ S, uint32_t m,
+__device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict__ U, const uint32_t *__restrict__ S, uint32_t m,
                            uint64_t *__restrict__ Unew, uint32_t *__restrict__ Snew, uint32_t *__restrict__ ISA,
                            uint32_t *__restrict__ SA, uint8_t *__restrict__ L, uint32_t *__restrict__ orig_out)
 {
@@ -280,7 +280,7 @@ __device__ uint32_t rerank(const uint64_t *__restrict__ U, const uint32_t *__res
 }
 
 // key2 = rank of the rotation h positions further on; fills the five digit histograms.
-__device__ void gather_keys(uint64_t *__restrict__ U, uint32_t m, const uint32_t *__restrict__ ISA, uint32_t n,
+__device__ __attribute__((noinline)) void gather_keys(uint64_t *__restrict__ U, uint32_t m, const uint32_t *__restrict__ ISA, uint32_t n,
                             uint32_t h)
 {
     const uint32_t tid = threadIdx.x;
@@ -400,7 +400,7 @@ __device__ __forceinline__ uint32_t seg_align(const uint64_t *__restrict__ U, ui
 
 // TEXT: key = block bytes [sa+h, sa+h+8) ; RANK: key2 = ISA[(sa+h) mod n] merged into the record.
 template <bool TEXT>
-__device__ void seg_sort_round(uint64_t *__restrict__ U, uint32_t m, const uint32_t *__restrict__ ISA,
+__device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ U, uint32_t m, const uint32_t *__restrict__ ISA,
                                const uint8_t *__restrict__ T, uint32_t n, uint32_t h, uint32_t bits = 8,
                                uint32_t csym = 8)
 {
