@@ -50,6 +50,13 @@ __shared__ uint32_t s_hist[5][256];
 __shared__ uint32_t s_base[256];
 __shared__ uint32_t s_wcnt[2][SORT_NW * 256];
 __shared__ uint32_t s_scratch[2 * SORT_NW];
+#define RADIX_STAGED 1
+#if RADIX_STAGED
+__shared__ uint64_t s_stage[SORT_NT * SORT_E];   // one tile of records, grouped by digit, for coalesced write-out
+__shared__ uint32_t s_lbase[256];                // tile-local start of every digit's run
+__shared__ uint32_t s_gbase[256];                // global start of every digit's run of this tile
+__shared__ uint32_t s_wpart[4];
+#endif
 __shared__ uint8_t s_seq[256];     // byte value -> dense symbol id (order preserving)
 __shared__ uint32_t s_inuse[256];
 __shared__ uint32_t s_bcast[4];   // [0] block index, [1] carry group start (+1), [2] carry count, [3] largest group
@@ -172,6 +179,49 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
             dig[e] = d;
         }
         bzx_lds_barrier();
+#if RADIX_STAGED
+        if (tid < 256) {
+            // cross-wave exclusive counts of digit tid inside this tile, tile total, global start
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < SORT_NW; w++) {
+                const uint32_t t = s_wcnt[cur][w * 256 + tid];
+                s_wcnt[cur][w * 256 + tid] = run;
+                run += t;
+            }
+            s_gbase[tid] = s_base[tid];
+            s_base[tid] += run;
+            const uint32_t incl = bzx_wave_incl_sum(run);     // exclusive prefix over digits: within my wave ...
+            s_lbase[tid] = incl - run;
+            if (lane == 63) s_wpart[wave] = incl;             // ... plus the totals of the waves before (added below)
+        }
+        for (uint32_t i = tid; i < SORT_NW * 256; i += SORT_NT) s_wcnt[cur ^ 1][i] = 0;
+        bzx_lds_barrier();
+        const uint32_t wp1 = s_wpart[0], wp2 = wp1 + s_wpart[1], wp3 = wp2 + s_wpart[2];
+#pragma unroll
+        for (int e = 0; e < SORT_E; e++) {
+            const uint32_t idx = wbase + e * 64 + lane;
+            if (idx < m) {
+                const uint32_t d = dig[e], q = d >> 6;
+                const uint32_t lb = s_lbase[d] + (q == 0 ? 0u : q == 1 ? wp1 : q == 2 ? wp2 : wp3);
+                s_stage[lb + wc[d] + off[e]] = rec[e];
+            }
+        }
+        bzx_lds_barrier();
+        {
+            const uint32_t tile_n = (m - t0 < SORT_NT * SORT_E) ? m - t0 : SORT_NT * SORT_E;
+#pragma unroll
+            for (int e = 0; e < SORT_E; e++) {
+                const uint32_t kpos = e * SORT_NT + tid;
+                if (kpos < tile_n) {
+                    const uint64_t r = s_stage[kpos];
+                    const uint32_t d = (uint32_t)(r >> shift) & 255u, q = d >> 6;
+                    const uint32_t lb = s_lbase[d] + (q == 0 ? 0u : q == 1 ? wp1 : q == 2 ? wp2 : wp3);
+                    dst[s_gbase[d] + (kpos - lb)] = r;
+                }
+            }
+        }
+#else
         if (tid < 256) {
             uint32_t run = s_base[tid];
 #pragma unroll
@@ -189,6 +239,7 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
             const uint32_t idx = wbase + e * 64 + lane;
             if (idx < m) dst[wc[dig[e]] + off[e]] = rec[e];
         }
+#endif
         cur ^= 1;
     }
     __syncthreads();
