@@ -72,9 +72,19 @@ __shared__ uint32_t e_tabbits[8];
 __shared__ uint32_t e_scratch[2 * EMIT_NW];
 __shared__ uint32_t e_bcast[4];
 
+#define EMIT_STAMP(slot)                                                      \
+    do {                                                                      \
+        if (B.dbg && tid == 0) {                                              \
+            const unsigned long long now_ = wall_clock64();                   \
+            atomicAdd(&B.dbg[slot], now_ - t_last);                           \
+            t_last = now_;                                                    \
+        }                                                                     \
+    } while (0)
+
 __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
 {
     const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
+    unsigned long long t_last = 0;
 
     for (;;) {
         if (tid == 0) e_bcast[0] = atomicAdd(&B.counters[3], 1u);
@@ -84,6 +94,7 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
         if (j_ >= B.nblk) break;
         const uint32_t b = B.blk_first + j_ * B.blk_step;
 
+        if (B.dbg && tid == 0) t_last = wall_clock64();
         const BzxBlock d = B.blk[b];
         const uint32_t alpha = d.n_in_use + 2, n_mtf = d.n_mtf, n_sel = d.n_selectors, n_groups = d.n_groups;
         const uint16_t *__restrict__ V = B.mtfv + (size_t)b * BZX_BLK_STRIDE;
@@ -132,6 +143,7 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
             w.finish();
         }
 
+        EMIT_STAMP(48);
         // ---- (b) selectors, unary (huffman.rs:237-292)
         {
             const uint32_t per = (n_sel + EMIT_NT - 1) / EMIT_NT;
@@ -152,6 +164,7 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
             }
         }
 
+        EMIT_STAMP(49);
         // ---- (c) coding tables, delta coded (huffman.rs:391-438), one lane per table
         if (lane == 0 && wave < n_groups) {
             uint32_t bits = 5;
@@ -186,6 +199,8 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
             w.finish();
         }
 
+        __syncthreads();
+        EMIT_STAMP(50);
         // ---- (d) payload (huffman.rs:452-466): one lane per group, offsets from a scan of group sizes
         {
             if (tid == 0) e_bcast[1] = 0;
@@ -221,6 +236,7 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
             }
         }
         __syncthreads();
+        EMIT_STAMP(51);
     }
 }
 

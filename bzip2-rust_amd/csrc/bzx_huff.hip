@@ -112,9 +112,19 @@ __device__ void make_code_lengths(int t, int32_t alpha, int32_t max_len)
     }
 }
 
+#define HUF_STAMP(slot)                                                       \
+    do {                                                                      \
+        if (B.dbg && tid == 0) {                                              \
+            const unsigned long long now_ = wall_clock64();                   \
+            atomicAdd(&B.dbg[slot], now_ - t_last);                           \
+            t_last = now_;                                                    \
+        }                                                                     \
+    } while (0)
+
 __global__ __launch_bounds__(HUF_NT) void bzx_huff_kernel(BzxBatch B)
 {
     const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
+    unsigned long long t_last = 0;
 
     for (;;) {
         if (tid == 0) h_bcast[0] = atomicAdd(&B.counters[2], 1u);
@@ -124,6 +134,7 @@ __global__ __launch_bounds__(HUF_NT) void bzx_huff_kernel(BzxBatch B)
         if (j_ >= B.nblk) break;
         const uint32_t b = B.blk_first + j_ * B.blk_step;
 
+        if (B.dbg && tid == 0) t_last = wall_clock64();
         const uint32_t n_mtf = B.blk[b].n_mtf;
         const uint32_t alpha = B.blk[b].n_in_use + 2;
         const uint16_t *__restrict__ V = B.mtfv + (size_t)b * BZX_BLK_STRIDE;
@@ -167,6 +178,7 @@ __global__ __launch_bounds__(HUF_NT) void bzx_huff_kernel(BzxBatch B)
         }
         __syncthreads();
 
+        HUF_STAMP(40);
         // ---- four refinement passes
         for (int iter = 0; iter < BZX_N_ITERS; iter++) {
             for (uint32_t i = tid; i < 6 * (BZX_MAX_ALPHA + 2); i += HUF_NT) (&h_rfreq[0][0])[i] = 0;
@@ -210,8 +222,10 @@ __global__ __launch_bounds__(HUF_NT) void bzx_huff_kernel(BzxBatch B)
                 }
             }
             __syncthreads();
+            HUF_STAMP(41);
             if (lane == 0 && wave < n_groups) make_code_lengths((int)wave, (int32_t)alpha, 17);
             __syncthreads();
+            HUF_STAMP(42);
         }
 
         // ---- canonical codes (huffman.rs:361-374), one lane per table
@@ -252,6 +266,7 @@ __global__ __launch_bounds__(HUF_NT) void bzx_huff_kernel(BzxBatch B)
         }
         __syncthreads();
 
+        HUF_STAMP(43);
         // ---- payload size per group under its final selector; total payload bits
         {
             uint32_t my_bits = 0;
@@ -260,12 +275,20 @@ __global__ __launch_bounds__(HUF_NT) void bzx_huff_kernel(BzxBatch B)
                 const uint32_t cnt = (n_mtf - gs < BZX_G_SIZE) ? n_mtf - gs : BZX_G_SIZE;
                 const uint32_t *__restrict__ vp = reinterpret_cast<const uint32_t *>(V + gs);
                 const uint32_t bt = SEL[g];
-                uint32_t acc = 0;
-                for (uint32_t k = 0; k < BZX_G_SIZE / 2; k++) {
-                    const uint32_t w = vp[k];
-                    if (2 * k < cnt) acc += h_len[bt][w & 0xffffu];
-                    if (2 * k + 1 < cnt) acc += h_len[bt][w >> 16];
+                uint32_t sy[BZX_G_SIZE / 2];
+#pragma unroll
+                for (int k = 0; k < BZX_G_SIZE / 2; k++) sy[k] = vp[k];
+                uint32_t accA = 0, accB = 0;
+#pragma unroll
+                for (int k = 0; k < BZX_G_SIZE; k++) {
+                    if ((uint32_t)k < cnt) {
+                        const uint32_t sm = (sy[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                        accA += h_lenA[sm];
+                        accB += h_lenB[sm];
+                    }
                 }
+                const uint32_t pick = bt < 3 ? accA : accB;
+                const uint32_t acc = (pick >> (10 * (bt % 3))) & 1023u;
                 GB[g] = (uint16_t)acc;
                 my_bits += acc;
             }
@@ -274,36 +297,59 @@ __global__ __launch_bounds__(HUF_NT) void bzx_huff_kernel(BzxBatch B)
             if (tid == 0) h_acc[2] = tot;
         }
 
+        HUF_STAMP(44);
         // ---- selector MTF (huffman.rs:237-292): chunk per lane, start list rebuilt from earlier chunks
         {
             const uint32_t per = (n_sel + HUF_NT - 1) / HUF_NT;
             const uint32_t lo = tid * per;
             const uint32_t hi = lo + per < n_sel ? lo + per : n_sel;
-            // start list: symbols by most recent occurrence before lo, then never-seen ascending
-            uint8_t pos[6];
-            uint32_t cnt = 0, seen = 0;
-            for (uint32_t i = lo < n_sel ? lo : n_sel; i > 0 && cnt < n_groups;) {
-                i--;
-                const uint32_t s = SEL[i];
-                if (!((seen >> s) & 1u)) {
-                    seen |= 1u << s;
-                    pos[cnt++] = (uint8_t)s;
-                }
+            // last use (1 + selector index) of every table inside my chunk, then an exclusive max-scan over the
+            // lanes: lp[t] = last use of table t before my chunk (0 = never)
+            uint32_t lp[6] = {0, 0, 0, 0, 0, 0};
+            for (uint32_t i = lo; i < hi; i++) {
+                const uint32_t sg = SEL[i];
+#pragma unroll
+                for (uint32_t t = 0; t < 6; t++)
+                    if (sg == t) lp[t] = i + 1;
             }
-            for (uint32_t s = 0; s < n_groups && cnt < n_groups; s++)
-                if (!((seen >> s) & 1u)) pos[cnt++] = (uint8_t)s;
+#pragma unroll
+            for (uint32_t t = 0; t < 6; t++) {
+                uint32_t d0, d1, ex, tt;
+                bzx_block_scan_sum_max<HUF_NT>(0u, lp[t], h_scratch, d0, d1, ex, tt);
+                lp[t] = ex;
+            }
+            // start list (nibble k = k-th entry): tables by most recent use before lo, then never-used ascending
+            uint32_t st = 0, cnt = 0, taken = 0;
+            for (uint32_t r = 0; r < n_groups; r++) {
+                uint32_t best = 0, bt = 6;
+#pragma unroll
+                for (uint32_t t = 0; t < 6; t++)
+                    if (t < n_groups && !((taken >> t) & 1u) && lp[t] > best) {
+                        best = lp[t];
+                        bt = t;
+                    }
+                if (bt == 6) break;
+                taken |= 1u << bt;
+                st |= bt << (4 * cnt);
+                cnt++;
+            }
+            for (uint32_t sg = 0; sg < n_groups; sg++)
+                if (!((taken >> sg) & 1u)) {
+                    st |= sg << (4 * cnt);
+                    cnt++;
+                }
+            st |= 0xFFFFFFFFu << (4 * n_groups);      // unused nibbles never match a table number
             uint32_t my_bits = 0;
             for (uint32_t i = lo; i < hi; i++) {
-                const uint8_t ll = SEL[i];
-                uint32_t j = 0;
-                uint8_t tmp = pos[0];
-                while (ll != tmp) {
-                    j++;
-                    const uint8_t t2 = tmp;
-                    tmp = pos[j];
-                    pos[j] = t2;
+                const uint32_t ll = SEL[i];
+                const uint32_t x = st ^ (ll * 0x11111111u);
+                const uint32_t z = (x - 0x11111111u) & ~x & 0x88888888u;       // lowest flagged nibble = first match
+                const uint32_t j = (uint32_t)(__ffs((int)z) - 1) >> 2;
+                if (j) {
+                    const uint32_t lowmask = (1u << (4 * j)) - 1u;
+                    const uint32_t himask = ~((1u << (4 * (j + 1))) - 1u);
+                    st = (st & himask) | ((st & lowmask) << 4) | ll;
                 }
-                pos[0] = tmp;
                 SELM[i] = (uint8_t)j;
                 my_bits += j + 1;
             }
@@ -313,6 +359,7 @@ __global__ __launch_bounds__(HUF_NT) void bzx_huff_kernel(BzxBatch B)
         }
         __syncthreads();
 
+        HUF_STAMP(45);
         if (tid == 0) {
             uint32_t map_words = 0;
             for (uint32_t i = 0; i < 16; i++) {
