@@ -268,7 +268,7 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     if ((stages & STG_MTF) && nblk) bzx_launch_mtf(B, grid_for(ctx, nblk, 1), ctx->stream);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    if ((stages & STG_HUF) && nblk) bzx_launch_huffman(B, grid_for(ctx, nblk, 2), ctx->stream);
+    if ((stages & STG_HUF) && nblk) bzx_launch_huffman(B, grid_for(ctx, nblk, 3), ctx->stream);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     if (stages & STG_EMIT) {
         if (out_level == 0) {

@@ -618,8 +618,11 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
             const uint32_t i = t0 + tid;
             const bool valid = i < n;
             const uint32_t key = valid ? pack_symbols32(text_key8(T, n, i), bits, ksym) : 0u;
+            // packed symbol keys spread over the digits: plain LDS atomics (no wave aggregation needed)
+            if (valid) {
 #pragma unroll
-            for (int p = 0; p < 4; p++) hist_add(s_hist[p], (key >> (8 * p)) & 255u, valid);
+                for (int p = 0; p < 4; p++) atomicAdd(&s_hist[p][(key >> (8 * p)) & 255u], 1u);
+            }
         }
         __syncthreads();
         PHASE_STAMP(0);
