@@ -372,8 +372,8 @@ __device__ __attribute__((noinline)) void gather_keys(uint64_t *__restrict__ U, 
 // the tile by (g, key) with a register / cross-lane bitonic network and writes it back in place.
 // No LDS, no workgroup barriers; HBM traffic is one 8-byte read + one 8-byte write per record plus the
 // key fetch.
-#define SEG_T 512
-#define SEG_PER_LANE 8
+#define SEG_T 512            // RANK tiles: 8 records per lane
+#define SEG_T_TEXT 256       // TEXT tiles: 4 two-word records per lane (keeps the tile in registers)
 
 struct SegRec {
     uint64_t rec;   // memory record
@@ -386,10 +386,11 @@ __device__ __forceinline__ bool seg_less(const SegRec &a, const SegRec &b)
     return ga < gb || (ga == gb && (a.key < b.key || (a.key == b.key && a.rec < b.rec)));
 }
 
-template <bool TEXT> __device__ __forceinline__ void bitonic512(SegRec (&v)[SEG_PER_LANE], uint32_t lane)
+template <bool TEXT, int SEG_PER_LANE> __device__ __forceinline__ void bitonic_tile(SegRec (&v)[SEG_PER_LANE], uint32_t lane)
 {
+    constexpr uint32_t SEG_TILE = 64 * SEG_PER_LANE;
 #pragma unroll
-    for (uint32_t k = 2; k <= SEG_T; k <<= 1) {
+    for (uint32_t k = 2; k <= SEG_TILE; k <<= 1) {
 #pragma unroll
         for (uint32_t st = k >> 1; st > 0; st >>= 1) {
             if (st >= SEG_PER_LANE) {
@@ -426,7 +427,8 @@ template <bool TEXT> __device__ __forceinline__ void bitonic512(SegRec (&v)[SEG_
     }
 }
 
-// first group start at or after r0 (groups have <= SEG_T members), or m
+// first group start at or after r0 (groups have <= 64*SEG_PER_LANE members), or m
+template <int SEG_PER_LANE>
 __device__ __forceinline__ uint32_t seg_align(const uint64_t *__restrict__ U, uint32_t m, uint32_t r0, uint32_t lane)
 {
     if (r0 == 0) return 0;
@@ -450,18 +452,19 @@ __device__ __forceinline__ uint32_t seg_align(const uint64_t *__restrict__ U, ui
 }
 
 // TEXT: key = block bytes [sa+h, sa+h+8) ; RANK: key2 = ISA[(sa+h) mod n] merged into the record.
-template <bool TEXT>
+template <bool TEXT, int SEG_PER_LANE>
 __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ U, uint32_t m, const uint32_t *__restrict__ ISA,
                                const uint8_t *__restrict__ T, uint32_t n, uint32_t h, uint32_t bits = 8,
                                uint32_t csym = 8)
 {
+    constexpr uint32_t SEG_TILE = 64 * SEG_PER_LANE;
     const uint32_t lane = bzx_lane(), wave = bzx_wave();
     const uint32_t share = (m + SORT_NW - 1) / SORT_NW;
-    uint32_t a = seg_align(U, m, wave * share < m ? wave * share : m, lane);
-    const uint32_t end = seg_align(U, m, (wave + 1) * share < m ? (wave + 1) * share : m, lane);
+    uint32_t a = seg_align<SEG_PER_LANE>(U, m, wave * share < m ? wave * share : m, lane);
+    const uint32_t end = seg_align<SEG_PER_LANE>(U, m, (wave + 1) * share < m ? (wave + 1) * share : m, lane);
     const uint32_t hmod = h % n;
     while (a < end) {
-        const uint32_t lim = (end - a < SEG_T) ? end : a + SEG_T;     // tile may reach at most lim
+        const uint32_t lim = (end - a < SEG_TILE) ? end : a + SEG_TILE;     // tile may reach at most lim
         SegRec v[SEG_PER_LANE];
 #pragma unroll
         for (int j = 0; j < SEG_PER_LANE; j++) {
@@ -527,7 +530,7 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
                 v[j].key = ~0ull;
             }
         }
-        bitonic512<TEXT>(v, lane);
+        bitonic_tile<TEXT, SEG_PER_LANE>(v, lane);
         if (TEXT) {
             // tile-local index of the first member of every new (g, key) group -> record bits 28..37
             SegRec pl;                                     // last element of the previous lane
@@ -643,9 +646,9 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
 
         // ---- TEXT rounds: csym more symbols per round, tiles only
         uint32_t depth = ksym, round = 0;
-        while (m > 0 && depth < n && round < TEXT_ROUNDS && s_bcast[3] <= SEG_T) {
+        while (m > 0 && depth < n && round < TEXT_ROUNDS && s_bcast[3] <= SEG_T_TEXT) {
             __syncthreads();
-            seg_sort_round<true>(ua, m, nullptr, T, n, depth, bits, csym);
+            seg_sort_round<true, 4>(ua, m, nullptr, T, n, depth, bits, csym);
             PHASE_STAMP(8 + round * 3);
             m = rerank<MODE_TEXT>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out);
             PHASE_STAMP(9 + round * 3);
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
                 const uint32_t maxgrp = s_bcast[3];
                 __syncthreads();
                 if (maxgrp <= SEG_T) {
-                    seg_sort_round<false>(ua, m, ws.isa, T, n, h);
+                    seg_sort_round<false, 8>(ua, m, ws.isa, T, n, h);
                     m = rerank<MODE_RANK>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out);
                     uint64_t *tu = ua; ua = ub; ub = tu;
                 } else {
