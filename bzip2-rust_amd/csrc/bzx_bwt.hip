@@ -265,14 +265,23 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
     }
     __syncthreads();
     uint32_t my_maxgrp = 0;
+    // software pipeline: the records of the next tile are loaded while this one is scanned and stored; the
+    // barriers of the loop order LDS only
+    uint64_t nx[SORT_E + 2];
+#pragma unroll
+    for (int j = 0; j < SORT_E + 2; j++) {
+        const uint32_t kk = tid * SORT_E + j;   // nx[j] holds U[kk - 1]
+        nx[j] = (kk >= 1 && kk - 1 < m) ? U[kk - 1] : 0ull;
+    }
     for (uint32_t t0 = 0; t0 < m; t0 += SORT_NT * SORT_E) {
         const uint32_t k0 = t0 + tid * SORT_E;
         const uint32_t carry_ks = s_bcast[1], carry_cnt = s_bcast[2];
         uint64_t r[SORT_E + 2];
 #pragma unroll
         for (int j = 0; j < SORT_E + 2; j++) {
-            const uint32_t kk = k0 + j;   // r[j] holds U[kk - 1]
-            r[j] = (kk >= 1 && kk - 1 < m) ? U[kk - 1] : 0ull;
+            r[j] = nx[j];
+            const uint32_t kk = k0 + SORT_NT * SORT_E + j;
+            nx[j] = (kk - 1 < m) ? U[kk - 1] : 0ull;
         }
         bool f[SORT_E + 1];
 #pragma unroll
@@ -290,7 +299,7 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
             }
         }
         uint32_t cnt_excl, cnt_total, ks_excl, ks_total;
-        bzx_block_scan_sum_max<SORT_NT>(my_cnt, my_ks, s_scratch, cnt_excl, cnt_total, ks_excl, ks_total);
+        bzx_block_scan_sum_max_lds<SORT_NT>(my_cnt, my_ks, s_scratch, cnt_excl, cnt_total, ks_excl, ks_total);
         uint32_t ks = ks_excl ? ks_excl : carry_ks;
         uint32_t o = carry_cnt + cnt_excl;
 #pragma unroll
@@ -321,7 +330,7 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
             if (ks_total) s_bcast[1] = ks_total;
             s_bcast[2] = carry_cnt + cnt_total;
         }
-        __syncthreads();
+        bzx_lds_barrier();
     }
     atomicMax(&s_bcast[3], my_maxgrp);
     __syncthreads();

@@ -104,3 +104,38 @@ __device__ __forceinline__ void bzx_block_scan_sum_max(uint32_t sum_v, uint32_t 
     max_excl = m_prev > mpre ? m_prev : mpre;
     max_total = mtot;
 }
+
+// Same, but the two barriers order LDS only (global loads/stores of the caller stay in flight).
+// scratch: 2*NT/64 words.  max_v uses 0 as the identity.
+template <int NT>
+__device__ __forceinline__ void bzx_block_scan_sum_max_lds(uint32_t sum_v, uint32_t max_v, uint32_t *scratch,
+                                                       uint32_t &sum_excl, uint32_t &sum_total,
+                                                       uint32_t &max_excl, uint32_t &max_total)
+{
+    const uint32_t lane = bzx_lane(), w = bzx_wave();
+    const uint32_t si = bzx_wave_incl_sum(sum_v);
+    const uint32_t mi = bzx_wave_incl_max(max_v);
+    uint32_t m_prev = __shfl_up(mi, 1);       // exclusive max within the wave
+    if (lane == 0) m_prev = 0;
+    if (lane == 63) {
+        scratch[w] = si;
+        scratch[NT / 64 + w] = mi;
+    }
+    bzx_lds_barrier();
+    uint32_t pre = 0, tot = 0, mpre = 0, mtot = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < NT / 64; i++) {
+        const uint32_t t = scratch[i], m = scratch[NT / 64 + i];
+        if (i < w) {
+            pre += t;
+            if (m > mpre) mpre = m;
+        }
+        tot += t;
+        if (m > mtot) mtot = m;
+    }
+    bzx_lds_barrier();
+    sum_excl = pre + si - sum_v;
+    sum_total = tot;
+    max_excl = m_prev > mpre ? m_prev : mpre;
+    max_total = mtot;
+}
