@@ -330,13 +330,18 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         }
         __syncthreads();
         uint32_t hot0 = 0, hot1 = 0, hot2 = 0;      // RUNA, RUNB and symbol 2 (rank 1) counted in registers
+        // software pipeline: the rank bytes of the next tile are loaded while this one is scanned and emitted;
+        // the barriers inside the loop order LDS only
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (tid * MTF_E < n) nxt = *reinterpret_cast<const uint4 *>(R + tid * MTF_E);   // bytes past n are ignored below
         for (uint32_t t0 = 0; t0 < n; t0 += MTF_NT * MTF_E) {
             const uint32_t i0 = t0 + tid * MTF_E;
             const uint32_t carry_p1 = m_bcast[1], carry_out = m_bcast[2];
-            uint32_t w[4] = {0, 0, 0, 0};
-            if (i0 < n) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(R + i0);   // bytes past n are ignored below
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
+            {
+                const uint32_t i1 = i0 + MTF_NT * MTF_E;
+                nxt = make_uint4(0, 0, 0, 0);
+                if (i1 < n) nxt = *reinterpret_cast<const uint4 *>(R + i1);
             }
             // last nonzero position (+1) inside my 16 bytes
             uint32_t my_p1 = 0;
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
                 if (i < n && r != 0) my_p1 = i + 1;
             }
             uint32_t dummy_s, dummy_t, p1_excl, p1_total;
-            bzx_block_scan_sum_max<MTF_NT>(0u, my_p1, m_scratch, dummy_s, dummy_t, p1_excl, p1_total);
+            bzx_block_scan_sum_max_lds<MTF_NT>(0u, my_p1, m_scratch, dummy_s, dummy_t, p1_excl, p1_total);
             const uint32_t p1_in = p1_excl ? p1_excl : carry_p1;
             // count my output symbols
             uint32_t p1 = p1_in, my_cnt = 0;
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
                 }
             }
             uint32_t cnt_total;
-            const uint32_t cnt_excl = bzx_block_excl_sum<MTF_NT>(my_cnt, m_scratch, cnt_total);
+            const uint32_t cnt_excl = bzx_block_excl_sum_lds<MTF_NT>(my_cnt, m_scratch, cnt_total);
             // emit
             uint32_t o = carry_out + cnt_excl;
             p1 = p1_in;
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
                 if (p1_total) m_bcast[1] = p1_total;
                 m_bcast[2] = carry_out + cnt_total;
             }
-            __syncthreads();
+            bzx_lds_barrier();
         }
         if (hot0) atomicAdd(&m_freq[0], hot0);
         if (hot1) atomicAdd(&m_freq[1], hot1);

@@ -139,3 +139,24 @@ __device__ __forceinline__ void bzx_block_scan_sum_max_lds(uint32_t sum_v, uint3
     max_excl = m_prev > mpre ? m_prev : mpre;
     max_total = mtot;
 }
+
+// Same with LDS-only barriers.
+template <int NT>
+__device__ __forceinline__ uint32_t bzx_block_excl_sum_lds(uint32_t v, uint32_t *scratch, uint32_t &total)
+{
+    const uint32_t incl = bzx_wave_incl_sum(v);
+    if (bzx_lane() == 63) scratch[bzx_wave()] = incl;
+    bzx_lds_barrier();
+    uint32_t pre = 0, tot = 0;
+    const uint32_t w = bzx_wave();
+#pragma unroll
+    for (uint32_t i = 0; i < NT / 64; i++) {
+        const uint32_t t = scratch[i];
+        if (i < w) pre += t;
+        tot += t;
+    }
+    bzx_lds_barrier();
+    total = tot;
+    return pre + incl - v;
+}
+
