@@ -1,0 +1,51 @@
+"""CPU tests (-m "not gpu"): kernel LOGIC through the fiber emulator (tests/emu).
+
+The HIP sources in bzip2-rust_amd/csrc are compiled with g++ against tests/emu/hip/hip_runtime.h (workgroups as
+fibers, wave64 collectives, LDS as static storage) and driven through the same C ABI as on the GPU.  This proves
+indexing, scans and loop bounds of the kernels on small inputs in the GPU-less build container; it proves
+nothing about the device (memory ordering, performance) -- the -m gpu suite does that."""
+import bz2
+import os
+import random
+import subprocess
+
+import pytest
+
+from bzx_ctypes import EMU_PATH, ROOT, BzxLib
+
+
+@pytest.fixture(scope="module")
+def emu():
+    csrc = os.path.join(ROOT, "bzip2-rust_amd", "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(ROOT, "tests", "emu", "hip", "hip_runtime.h")]
+    if not os.path.exists(EMU_PATH) or any(os.path.getmtime(s) > os.path.getmtime(EMU_PATH) for s in srcs):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+    lib = BzxLib(EMU_PATH)
+    yield lib
+    lib.close()
+
+
+def test_emu_stages_small(emu, oracle):
+    rnd = random.Random(4)
+    cases = [b"a", b"aa", b"banana", b"Making a silly test.", oracle.synthtext(3000), rnd.randbytes(2500),
+             bytes(rnd.choice(b"ab") for _ in range(3000)), b"abcabcd" * 15, b"\0\0\0\0\xfb" * 300 + b"\0\0\0\0\x07",
+             oracle.synthtext(1500) * 2 + b"z"]
+    for blk in cases:
+        L, orig, _ = emu.stage_bwt(blk)
+        assert (L, orig) == oracle.bwt(blk)
+        mo, fo, iuo, niu = oracle.mtf(L)
+        assert emu.stage_mtf(L) == (mo, fo, iuo)
+        assert emu.stage_huffman(mo, fo, niu + 2) == oracle.huff(mo, fo, niu + 2)
+        crc = oracle.crc32(blk)
+        assert emu.compress_block(blk, crc) == oracle.compress_block(blk, crc)
+
+
+def test_emu_split_and_stream(emu, oracle):
+    rnd = random.Random(8)
+    runs = bytearray()
+    while len(runs) < 150000:
+        runs += bytes([rnd.choice(b"ab\0")]) * rnd.randint(1, 400)
+    for data, level in ((oracle.synthtext(130000), 1), (bytes(runs), 1), (b"", 9), (b"xyz", 9)):
+        assert emu.split_rle1(data, level) == oracle.split_rle1(data, level)
+    data = oracle.synthtext(60000) + b"\0" * 2000 + oracle.synthtext(45000)
+    assert emu.compress_buffer(data, 1) == bz2.compress(data, 1)
