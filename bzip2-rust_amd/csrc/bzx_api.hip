@@ -761,3 +761,17 @@ extern "C" int bzx_dbg_phase_timers(bzx_ctx *ctx, int enable, unsigned long long
     ctx->B.dbg = enable ? ctx->d_dbg : nullptr;
     return BZX_OK;
 }
+
+// Debug helper: per-block microseconds spent in the BWT kernel during the last run with phase timers enabled.
+extern "C" int bzx_dbg_block_times(bzx_ctx *ctx, uint32_t nblk, uint32_t *us_out, uint32_t *n_out, uint32_t *inuse_out)
+{
+    if (!ctx || !us_out || nblk > ctx->cap_blocks) return BZX_E_PARAM;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->h_blk, ctx->B.blk, nblk * sizeof(BzxBlock), hipMemcpyDeviceToHost));
+    for (uint32_t b = 0; b < nblk; b++) {
+        us_out[b] = ctx->h_blk[b].pad_[1];
+        if (n_out) n_out[b] = ctx->h_blk[b].n;
+        if (inuse_out) inuse_out[b] = ctx->h_blk[b].n_in_use;
+    }
+    return BZX_OK;
+}

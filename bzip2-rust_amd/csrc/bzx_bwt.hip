@@ -246,13 +246,14 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
 }
 
 // Re-rank the sorted records U[0..m): a new group starts wherever the group key (rec >> KEY_SHIFT) changes.
-// new rank = SA position of the group's first member; SA[pos] = sa; in INIT/TEXT mode L[pos] = preceding byte,
-// in RANK mode ISA[sa] = rank.  Members of groups of size > 1 are compacted to Unew/Snew (slot = SA position).
+// new rank = SA position of the group's first member; SA[pos] = sa; L[pos] = preceding byte (from the record in
+// INIT/TEXT mode, from the block in RANK mode); in RANK mode also ISA[sa] = rank.  Members of groups of size > 1 are compacted to Unew/Snew (slot = SA position).
 // Returns the number of unresolved rotations; s_bcast[3] = size of the largest group.
 template <int MODE>
 __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict__ U, const uint32_t *__restrict__ S, uint32_t m,
                            uint64_t *__restrict__ Unew, uint32_t *__restrict__ Snew, uint32_t *__restrict__ ISA,
-                           uint32_t *__restrict__ SA, uint8_t *__restrict__ L, uint32_t *__restrict__ orig_out)
+                           uint32_t *__restrict__ SA, uint8_t *__restrict__ L, uint32_t *__restrict__ orig_out,
+                           const uint8_t *__restrict__ T, uint32_t n)
 {
     constexpr int KEY_SHIFT = (MODE == MODE_RANK) ? RNK_KEY_SHIFT : TXT_KEY_SHIFT;
     constexpr int SA_SHIFT = (MODE == MODE_RANK) ? RNK_SA_SHIFT : TXT_SA_SHIFT;
@@ -314,8 +315,13 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
                 const uint32_t sa = (uint32_t)(rec >> SA_SHIFT) & 0xFFFFFu;
                 const uint32_t pos = INITIAL ? k : S[k];
                 SA[pos] = sa;
-                if (MODE == MODE_RANK) ISA[sa] = newrank;
-                else L[pos] = (uint8_t)rec;
+                if (MODE == MODE_RANK) {
+                    ISA[sa] = newrank;
+                    // RANK records carry no preceding byte: fetch it once, when the rotation's row is final
+                    if (f[j] && f[j + 1]) L[pos] = T[sa ? sa - 1 : n - 1];
+                } else {
+                    L[pos] = (uint8_t)rec;
+                }
                 if (sa == 0) *orig_out = pos;
                 if (!(f[j] && f[j + 1])) {
                     Unew[o] = (MODE == MODE_RANK)
@@ -577,6 +583,202 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
     __syncthreads();
 }
 
+// ---- large groups in TEXT mode ---------------------------------------------------------------------------
+// Real text leaves groups far larger than a wave tile after the initial key (tens of thousands of rotations
+// starting "self._" ...).  Instead of falling back to global radix passes, every such group is split by its
+// NEXT symbol, one wave per group: per-wave 256-bin histogram and cursors in LDS, a counting sort inside the
+// group's own range (order inside a bucket is irrelevant: its members are still tied).  Sub-groups that are
+// still larger than a tile are split again by the following symbol.  Splitting only strengthens the round
+// invariant (all members of a group agree on at least `depth` symbols), so the tile round that follows is
+// unchanged.
+#define BIG_MAX 3000         // big groups per pass (lists live in the ISA array, which TEXT mode does not use)
+#define BIG_PASSES 64
+#define BIG_COOP 4096        // groups above this size are split by the whole workgroup, smaller ones by one wave
+__shared__ uint32_t s_big[5];     // [0] groups in the current list, [1] in the next list, [2] overflow flag,
+                                  // [3] rotations in the current list's groups, [4] in the next list's groups
+
+__device__ __attribute__((noinline)) void big_find(const uint64_t *__restrict__ U, const uint32_t *__restrict__ S,
+                                                    uint32_t m, uint32_t *__restrict__ list)
+{
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        s_big[0] = 0;
+        s_big[1] = 0;
+        s_big[2] = 0;
+        s_big[3] = 0;
+        s_big[4] = 0;
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < m; k += SORT_NT) {
+        const uint64_t rec = U[k];
+        const uint32_t g = (uint32_t)(rec >> G_SHIFT);
+        const bool is_end = (k + 1 == m) || ((uint32_t)(U[k + 1] >> G_SHIFT) != g);
+        if (is_end) {
+            const uint32_t size = S[k] - g + 1;        // slots of a group are consecutive SA positions
+            if (size > SEG_T_TEXT) {
+                const uint32_t idx = atomicAdd(&s_big[0], 1u);
+                atomicAdd(&s_big[3], size);
+                if (idx < BIG_MAX) {
+                    list[2 * idx] = k + 1 - size;
+                    list[2 * idx + 1] = size;
+                } else {
+                    s_big[2] = 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ U, uint64_t *__restrict__ Utmp,
+                                                          const uint32_t *__restrict__ list, uint32_t nlist,
+                                                          uint32_t *__restrict__ next, const uint8_t *__restrict__ T,
+                                                          uint32_t n, uint32_t d)
+{
+    const uint32_t lane = bzx_lane(), wave = bzx_wave();
+    uint32_t *hist = &s_wcnt[0][wave * 256];     // counts, then bucket bases
+    uint32_t *cur = &s_wcnt[1][wave * 256];      // scatter cursors
+    const uint32_t dmod = d % n;
+    for (uint32_t li = wave; li < nlist; li += SORT_NW) {
+        const uint32_t ks = list[2 * li], size = list[2 * li + 1];
+        if (size > BIG_COOP) continue;          // handled by the whole workgroup below
+        for (uint32_t i = lane; i < 256; i += 64) hist[i] = 0;
+        bzx_wave_sync();
+        const uint32_t g0 = (uint32_t)(U[ks] >> G_SHIFT);
+        for (uint32_t o = lane; o < size; o += 64) {
+            uint32_t p = ((uint32_t)(U[ks + o] >> TXT_SA_SHIFT) & 0xFFFFFu) + dmod;
+            if (p >= n) p -= n;
+            atomicAdd(&hist[s_seq[T[p]]], 1u);
+        }
+        bzx_wave_sync();
+        // exclusive scan of the 256 counts: 4 digits per lane
+        uint32_t c[4], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            c[i] = hist[4 * lane + i];
+            sum += c[i];
+        }
+        uint32_t run = bzx_wave_incl_sum(sum) - sum;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            hist[4 * lane + i] = run;
+            cur[4 * lane + i] = run;
+            if (c[i] > SEG_T_TEXT) {
+                atomicAdd(&s_big[4], c[i]);
+                const uint32_t idx = atomicAdd(&s_big[1], 1u);
+                if (idx < BIG_MAX) {
+                    next[2 * idx] = ks + run;
+                    next[2 * idx + 1] = c[i];
+                } else {
+                    s_big[2] = 1;
+                }
+            }
+            run += c[i];
+        }
+        bzx_wave_sync();
+        for (uint32_t o = lane; o < size; o += 64) {
+            const uint64_t rec = U[ks + o];
+            uint32_t p = ((uint32_t)(rec >> TXT_SA_SHIFT) & 0xFFFFFu) + dmod;
+            if (p >= n) p -= n;
+            const uint32_t dg = s_seq[T[p]];
+            const uint32_t pos = atomicAdd(&cur[dg], 1u);
+            const uint64_t low = rec & ((1ull << TXT_KEY_SHIFT) - 1ull);          // sa | prev, tile slot cleared
+            Utmp[ks + pos] = ((uint64_t)(g0 + hist[dg]) << G_SHIFT) | low;
+        }
+        // all lanes' stores must have landed before the wave reads the range back
+#ifndef BZX_HIP_EMU
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        bzx_wave_sync();
+        for (uint32_t o = lane; o < size; o += 64) U[ks + o] = Utmp[ks + o];
+        bzx_wave_sync();
+    }
+    __syncthreads();
+    // very large groups: all lanes of the workgroup on one group at a time (same steps, block barriers)
+    {
+        const uint32_t tid = threadIdx.x;
+        uint32_t *bh = s_hist[0], *bc = s_hist[1];      // counts -> bases, cursors
+        for (uint32_t li = 0; li < nlist; li++) {
+            const uint32_t ks = list[2 * li], size = list[2 * li + 1];
+            if (size <= BIG_COOP) continue;
+            if (tid < 256) bh[tid] = 0;
+            __syncthreads();
+            const uint32_t g0 = (uint32_t)(U[ks] >> G_SHIFT);
+            for (uint32_t o = tid; o < size; o += SORT_NT) {
+                uint32_t p = ((uint32_t)(U[ks + o] >> TXT_SA_SHIFT) & 0xFFFFFu) + dmod;
+                if (p >= n) p -= n;
+                atomicAdd(&bh[s_seq[T[p]]], 1u);
+            }
+            __syncthreads();
+            uint32_t tot;
+            const uint32_t cnt = tid < 256 ? bh[tid] : 0u;
+            const uint32_t base = bzx_block_excl_sum<SORT_NT>(cnt, s_scratch, tot);
+            if (tid < 256) {
+                bh[tid] = base;
+                bc[tid] = base;
+                if (cnt > SEG_T_TEXT) {
+                    atomicAdd(&s_big[4], cnt);
+                    const uint32_t idx = atomicAdd(&s_big[1], 1u);
+                    if (idx < BIG_MAX) {
+                        next[2 * idx] = ks + base;
+                        next[2 * idx + 1] = cnt;
+                    } else {
+                        s_big[2] = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            for (uint32_t o = tid; o < size; o += SORT_NT) {
+                const uint64_t rec = U[ks + o];
+                uint32_t p = ((uint32_t)(rec >> TXT_SA_SHIFT) & 0xFFFFFu) + dmod;
+                if (p >= n) p -= n;
+                const uint32_t dg = s_seq[T[p]];
+                const uint32_t pos = atomicAdd(&bc[dg], 1u);
+                const uint64_t low = rec & ((1ull << TXT_KEY_SHIFT) - 1ull);
+                Utmp[ks + pos] = ((uint64_t)(g0 + bh[dg]) << G_SHIFT) | low;
+            }
+            __syncthreads();
+            for (uint32_t o = tid; o < size; o += SORT_NT) U[ks + o] = Utmp[ks + o];
+            __syncthreads();
+        }
+    }
+}
+
+// Splits every group with more than SEG_T_TEXT members.  Returns true when all groups fit a tile afterwards.
+__device__ __attribute__((noinline)) bool big_split(uint64_t *__restrict__ U, uint64_t *__restrict__ Utmp,
+                                                     const uint32_t *__restrict__ S, uint32_t m,
+                                                     uint32_t *__restrict__ scratch, const uint8_t *__restrict__ T,
+                                                     uint32_t n, uint32_t depth)
+{
+    uint32_t *la = scratch, *lb = scratch + 2 * BIG_MAX;
+    big_find(U, S, m, la);
+    for (uint32_t pass = 0; pass < BIG_PASSES; pass++) {
+        const uint32_t nlist = s_big[0], ovf = s_big[2], before = s_big[3];
+        __syncthreads();
+        if (ovf) return false;
+        if (nlist == 0) return true;
+        big_split_pass(U, Utmp, la, nlist, lb, T, n, depth + pass);
+        const uint32_t after = s_big[4];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_big[0] = s_big[1] < BIG_MAX ? s_big[1] : BIG_MAX;
+            s_big[1] = 0;
+            s_big[3] = after;
+            s_big[4] = 0;
+        }
+        __syncthreads();
+        // long common prefixes (runs, repeated records): single symbols do not separate them -- when a pass
+        // leaves more than 60 % of the rotations in oversized groups, leave the block to prefix doubling
+        if (after && (uint64_t)after * 10 > (uint64_t)before * 6) return false;
+        uint32_t *t = la;
+        la = lb;
+        lb = t;
+    }
+    const bool ok = s_big[0] == 0 && s_big[2] == 0;
+    __syncthreads();
+    return ok;
+}
+
 // diagnostic phase timers (B.dbg != null only in profiling runs): accumulate wall-clock ticks per phase
 #define PHASE_STAMP(slot)                                                     \
     do {                                                                      \
@@ -604,7 +806,8 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         const uint32_t n = B.blk[b].n;
         const uint8_t *__restrict__ T = BZX_BLOCK_PTR(B, B.blk[b]);
         uint8_t *__restrict__ L = B.bwt + (size_t)b * BZX_BLK_STRIDE;
-        if (B.dbg && tid == 0) t_last = wall_clock64();
+        unsigned long long t_blk0 = 0;
+        if (B.dbg && tid == 0) t_last = t_blk0 = wall_clock64();
 
         // ---- A: bytes in use -> dense symbol ids; symbols per key
         if (tid < 256) s_inuse[tid] = 0;
@@ -650,25 +853,34 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         uint64_t *ua = ws.u0, *ub = ws.u1;      // ua: current compacted records, ub: the other buffer
         uint32_t *sa_cur = ws.s0, *sa_alt = ws.s1;
         uint32_t *orig_out = &B.blk[b].orig_ptr;
-        uint32_t m = rerank<MODE_INIT>(ws.u1, nullptr, n, ua, sa_cur, ws.isa, ws.sa, L, orig_out);
+        uint32_t m = rerank<MODE_INIT>(ws.u1, nullptr, n, ua, sa_cur, ws.isa, ws.sa, L, orig_out, T, n);
         PHASE_STAMP(2);
 
-        // ---- TEXT rounds: csym more symbols per round, tiles only
+        // ---- TEXT rounds: csym more symbols per round; oversized groups are split by single symbols first
         uint32_t depth = ksym, round = 0;
-        while (m > 0 && depth < n && round < TEXT_ROUNDS && s_bcast[3] <= SEG_T_TEXT) {
+        while (m > 0 && depth < n && round < TEXT_ROUNDS) {
+            const uint32_t maxgrp = s_bcast[3];
             __syncthreads();
+            if (maxgrp > SEG_T_TEXT) {
+                const bool ok = big_split(ua, ub, sa_cur, m, ws.isa, T, n, depth);
+                PHASE_STAMP(10 + (round < 7 ? round : 7) * 3);
+                if (!ok) break;
+            }
             seg_sort_round<true, 4>(ua, m, nullptr, T, n, depth, bits, csym);
-            PHASE_STAMP(8 + round * 3);
-            m = rerank<MODE_TEXT>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out);
-            PHASE_STAMP(9 + round * 3);
+            PHASE_STAMP(8 + (round < 7 ? round : 7) * 3);
+            const uint32_t m_before = m;
+            m = rerank<MODE_TEXT>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out, T, n);
+            PHASE_STAMP(9 + (round < 7 ? round : 7) * 3);
             uint64_t *tu = ua; ua = ub; ub = tu;
             uint32_t *ts = sa_cur; sa_cur = sa_alt; sa_alt = ts;
             depth += csym;
             round++;
+            // long repeats: when a round resolves less than 30 % of what it was given, doubling is cheaper
+            if (round >= 2 && (uint64_t)m * 10 > (uint64_t)m_before * 7) break;
         }
         __syncthreads();
 
-        // ---- RANK rounds (deep repeats / large groups): build ISA once, then prefix doubling
+        // ---- RANK rounds (deep repeats): build ISA once, then prefix doubling on ranks
         if (m > 0 && depth < n) {
             for (uint32_t j = tid; j < n; j += SORT_NT) ws.isa[ws.sa[j]] = j;       // resolved rotations: final rank
             __syncthreads();
@@ -680,13 +892,14 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
                 ua[k] = ((uint64_t)g << G_SHIFT) | ((uint64_t)sa << RNK_SA_SHIFT);
             }
             __syncthreads();
+            PHASE_STAMP(5);
             uint32_t h = depth;
             while (m > 0 && h < n) {
                 const uint32_t maxgrp = s_bcast[3];
                 __syncthreads();
                 if (maxgrp <= SEG_T) {
                     seg_sort_round<false, 8>(ua, m, ws.isa, T, n, h);
-                    m = rerank<MODE_RANK>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out);
+                    m = rerank<MODE_RANK>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out, T, n);
                     uint64_t *tu = ua; ua = ub; ub = tu;
                 } else {
                     gather_keys(ua, m, ws.isa, n, h);
@@ -696,20 +909,20 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
                     radix_pass<false>(ua, ub, m, RNK_KEY_SHIFT + 16, s_hist[2]);
                     radix_pass<false>(ub, ua, m, RNK_KEY_SHIFT + 24, s_hist[3]);
                     radix_pass<false>(ua, ub, m, RNK_KEY_SHIFT + 32, s_hist[4]);
-                    m = rerank<MODE_RANK>(ub, sa_cur, m, ua, sa_alt, ws.isa, ws.sa, L, orig_out);
+                    m = rerank<MODE_RANK>(ub, sa_cur, m, ua, sa_alt, ws.isa, ws.sa, L, orig_out, T, n);
                 }
                 uint32_t *ts = sa_cur; sa_cur = sa_alt; sa_alt = ts;
                 h <<= 1;
             }
-            PHASE_STAMP(4);
-            // ---- F: last column and orig_ptr from the final SA
-            for (uint32_t j = tid; j < n; j += SORT_NT) {
-                const uint32_t sa = ws.sa[j];
-                L[j] = T[sa ? sa - 1 : n - 1];
-                if (sa == 0) *orig_out = j;
+            // rotations still tied (periodic block): their rows of L are tie-invariant, write them now
+            for (uint32_t k = tid; k < m; k += SORT_NT) {
+                const uint32_t sa = (uint32_t)(ua[k] >> RNK_SA_SHIFT) & 0xFFFFFu;
+                L[sa_cur[k]] = T[sa ? sa - 1 : n - 1];
             }
+            PHASE_STAMP(4);
         }
         PHASE_STAMP(3);
+        if (B.dbg && tid == 0) B.blk[b].pad_[1] = (uint32_t)((wall_clock64() - t_blk0) / 100);   // microseconds in this kernel
         if (tid == 0) {
             B.blk[b].status = (m > 0) ? BZX_ST_PERIODIC : 0u;
             if (m > 0) {

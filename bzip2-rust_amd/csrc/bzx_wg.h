@@ -13,6 +13,15 @@
 #define bzx_lds_barrier() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+// Wave-level ordering point: on the device the lanes of a wave execute each instruction together and LDS /
+// global accesses of one wave are issued in program order, so only the compiler must not reorder; the CPU
+// emulator runs lanes one after the other and needs a real rendezvous here.
+#ifdef BZX_HIP_EMU
+#define bzx_wave_sync() hipemu::wave_sync()
+#else
+#define bzx_wave_sync() __builtin_amdgcn_wave_barrier()
+#endif
+
 __device__ __forceinline__ uint32_t bzx_lane() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t bzx_wave() { return threadIdx.x >> 6; }
 
