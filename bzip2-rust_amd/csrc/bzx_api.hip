@@ -160,7 +160,6 @@ static int ensure_slots(bzx_ctx *ctx, uint32_t n_slots)
         h[i].sa = h[i].isa + BZX_MAX_N;
     }
     if ((rc = dev_alloc(ctx, ctx->slot_allocs, &ctx->B.sort_ws, (size_t)n_slots))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->slot_allocs, &ctx->B.mtf_ws, (size_t)n_slots * BZX_MTF_WS))) return rc;
     HIP_TRY(ctx, hipMemcpy(ctx->B.sort_ws, h.data(), n_slots * sizeof(BzxSortWs), hipMemcpyHostToDevice));
     ctx->n_slots = n_slots;
     ctx->B.n_slots = n_slots;

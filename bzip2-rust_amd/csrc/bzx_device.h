@@ -71,12 +71,10 @@ struct BzxBatch {
     uint16_t *gbits;        // [nblk][BZX_SEL_STRIDE]  payload bits of every 50-symbol group
     uint32_t *out;          // output bit buffer (zeroed), big-endian bit order
     BzxSortWs *sort_ws;     // [n_slots]
-    uint8_t *mtf_ws;        // [n_slots][BZX_MTF_WS]   recency lists of the MTF kernel
     uint32_t n_slots;
     unsigned long long *dbg; // optional [64] phase timers (100 MHz ticks), null in production
 };
 
-#define BZX_MTF_WS (72u * 1024u)
 #define BZX_OUT_STRIDE 921600u      // per-block output slab for the per-block entry points (bytes)
 
 // Scratch of the RLE1 / block splitter (bzx_rle1.hip).

@@ -30,6 +30,11 @@ def oracle():
 @pytest.fixture(scope="session")
 def bzx():
     """The product library on cuda:0.  No fallback: a missing .so or device is a hard failure."""
+    # torch bundles its own HIP runtime: initialise it first (as bench.py does) so that tests which hand torch
+    # device tensors to the C ABI share one runtime with libbzx.so
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     from bzx_ctypes import BzxLib
     lib = BzxLib()
     yield lib

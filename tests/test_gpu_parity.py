@@ -162,3 +162,43 @@ def test_random_and_zero_heavy_inputs(bzx, oracle):
     z = b"\0" * (48 << 20)          # 1 periodic block of 899,985 bytes + tail
     out = bzx.compress_buffer(z, 9)
     assert out == bz2.compress(z, 9)
+
+
+def test_shard_entry_points_single_rank(bzx, oracle):
+    """bzx_shard_prepare / bzx_shard_emit with world size 1 on the device: same stream as libbz2.
+    (World size 2 is covered on CPU over gloo in tests/test_shard_gloo.py.)"""
+    import ctypes as C
+    import torch
+    L = bzx.lib
+    L.bzx_shard_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32,
+                                    C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
+    L.bzx_shard_emit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    data = oracle.synthtext(5_000_000) + b"\0" * 70000 + oracle.randbytes(300000)
+    d_raw = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    bits = torch.zeros(64, dtype=torch.int64, device="cuda")
+    cap = len(data) + len(data) // 4 + 65536
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    nblk = C.c_uint32()
+    torch.cuda.synchronize()
+    bzx._check(L.bzx_shard_prepare(bzx.ctx, d_raw.data_ptr(), len(data), 9, 0, 1, C.byref(nblk), bits.data_ptr(), 64))
+    ol = C.c_size_t()
+    bzx._check(L.bzx_shard_emit(bzx.ctx, bits.data_ptr(), d_out.data_ptr(), cap, C.byref(ol)))
+    torch.cuda.synchronize()
+    out = d_out[:ol.value].cpu().numpy().tobytes()
+    assert nblk.value == 6 and out == bz2.compress(data, 9)
+
+
+def test_output_buffer_too_small(bzx, oracle):
+    import ctypes as C
+    from bzx_ctypes import BzxError
+    data = oracle.randbytes(200000)
+    out = C.create_string_buffer(1000)
+    ol = C.c_size_t()
+    rc = bzx.lib.bzx_compress_buffer(bzx.ctx, data, len(data), 9, out, 1000, C.byref(ol))
+    assert rc == -4 and ol.value > 200000           # BZX_E_OUTBUF, needed size reported
+    blk = oracle.synthtext(50000)
+    ob = C.create_string_buffer(100)
+    olen = C.c_size_t()
+    pad = C.c_uint8()
+    rc = bzx.lib.bzx_compress_block(bzx.ctx, blk, len(blk), oracle.crc32(blk), ob, 100, C.byref(olen), C.byref(pad))
+    assert rc == -4
