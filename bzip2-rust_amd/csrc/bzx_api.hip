@@ -30,6 +30,10 @@ void bzx_split_launch_scatter(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t 
 uint32_t bzx_bwt_max_blocks_per_cu();
 void bzx_launch_bits_export(const BzxBatch &B, long long *bits, hipStream_t stream);
 void bzx_launch_bits_import(const BzxBatch &B, const long long *bits, hipStream_t stream);
+void bzx_launch_pack_layout(const BzxBatch &B, uint32_t first, uint32_t step, uint32_t nown, uint64_t *d_total,
+                            hipStream_t stream);
+void bzx_launch_unpack(const BzxBatch &B, const uint32_t *packed, uint32_t first, uint32_t step, uint32_t nown,
+                       uint32_t grid, hipStream_t stream);
 
 struct bzx_ctx {
     int device = 0;
@@ -687,35 +691,52 @@ extern "C" int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, in
     return BZX_OK;
 }
 
-extern "C" int bzx_shard_emit(bzx_ctx *ctx, const long long *d_bits_all, void *d_out, size_t cap, size_t *out_len)
+extern "C" int bzx_ctx_sync(bzx_ctx *ctx)
 {
-    if (!ctx || !d_bits_all || !d_out || !out_len || ((uintptr_t)d_out & 3u)) return BZX_E_PARAM;
+    if (!ctx) return BZX_E_PARAM;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BZX_OK;
+}
+
+static uint32_t shard_count(uint32_t nblk, uint32_t rank, uint32_t world)
+{
+    return nblk > rank ? (nblk - rank + world - 1) / world : 0;
+}
+
+extern "C" int bzx_shard_emit_packed(bzx_ctx *ctx, const long long *d_bits_all, void *d_packed, size_t cap,
+                                     size_t *packed_len, size_t *stream_len)
+{
+    if (!ctx || !d_bits_all || !d_packed || !packed_len || !stream_len || ((uintptr_t)d_packed & 3u)) return BZX_E_PARAM;
     if (ctx->shard_level == 0) return BZX_E_STATE;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     BzxBatch &B = ctx->B;
     const uint32_t nblk = ctx->shard_total, rank = ctx->shard_rank, world = ctx->shard_world;
+    const uint32_t mine = shard_count(nblk, rank, world);
     B.nblk = nblk;
     B.blk_first = 0;
     B.blk_step = 1;
-    B.out = (uint32_t *)d_out;
+    B.packed = 0;
     if (nblk) bzx_launch_bits_import(B, d_bits_all, ctx->stream);
-    bzx_launch_layout(B, 32, 0, ctx->d_scalars, ctx->stream);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    bzx_launch_layout(B, 32, 0, ctx->d_scalars, ctx->stream);                              // final positions of ALL blocks
+    bzx_launch_pack_layout(B, rank, world, mine, ctx->d_scalars + 2, ctx->stream);         // my packed positions
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t out_bytes = (ctx->h_scalars[0] + 80 + 7) >> 3;
-    const uint64_t need = (out_bytes + 3) & ~3ull;
-    if (need > (cap & ~(size_t)3)) {
-        ctx->err = "output buffer too small for the compressed stream";
+    const uint64_t need = ctx->h_scalars[2] * 4;
+    if (need > cap) {
+        ctx->err = "packed buffer too small for this rank's blocks";
         return BZX_E_OUTBUF;
     }
-    HIP_TRY(ctx, hipMemsetAsync(d_out, 0, need, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_packed, 0, need, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 64 * sizeof(uint32_t), ctx->stream));
-    if (rank == 0) bzx_launch_stream_frame(B, ctx->shard_level, ctx->d_scalars, ctx->d_scalars + 1, ctx->stream);
-    const uint32_t mine = nblk > rank ? (nblk - rank + world - 1) / world : 0;
+    B.out = (uint32_t *)d_packed;
     B.nblk = mine;
     B.blk_first = rank;
     B.blk_step = world;
+    B.packed = 1;
     if (mine) bzx_launch_emit(B, grid_for(ctx, mine, 2), ctx->stream);
+    B.packed = 0;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     if (nblk) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_blk, B.blk, nblk * sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream));
@@ -724,7 +745,8 @@ extern "C" int bzx_shard_emit(bzx_ctx *ctx, const long long *d_bits_all, void *d
     B.nblk = nblk;
     B.blk_first = 0;
     B.blk_step = 1;
-    *out_len = (size_t)out_bytes;
+    *packed_len = (size_t)need;
+    *stream_len = (size_t)out_bytes;
     // stats over my blocks
     bzx_stats &st = ctx->stats;
     collect_stage_times(ctx);
@@ -742,6 +764,45 @@ extern "C" int bzx_shard_emit(bzx_ctx *ctx, const long long *d_bits_all, void *d
     st.out_bits = out_bytes * 8;
     (void)hipEventElapsedTime(&st.ms_split, ctx->ev[5], ctx->ev[6]);
     (void)hipEventElapsedTime(&st.ms_total, ctx->ev[5], ctx->ev[7]);
+    return BZX_OK;
+}
+
+extern "C" int bzx_shard_assemble_begin(bzx_ctx *ctx, void *d_out, size_t cap, size_t *stream_len)
+{
+    if (!ctx || !d_out || ((uintptr_t)d_out & 3u)) return BZX_E_PARAM;
+    if (ctx->shard_level == 0) return BZX_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BzxBatch &B = ctx->B;
+    B.nblk = ctx->shard_total;
+    B.blk_first = 0;
+    B.blk_step = 1;
+    B.out = (uint32_t *)d_out;
+    const uint64_t out_bytes = (ctx->h_scalars[0] + 80 + 7) >> 3;      // total bits from bzx_shard_emit_packed
+    const uint64_t need = (out_bytes + 3) & ~3ull;
+    if (need > (cap & ~(size_t)3)) {
+        ctx->err = "output buffer too small for the compressed stream";
+        return BZX_E_OUTBUF;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(d_out, 0, need, ctx->stream));
+    bzx_launch_stream_frame(B, ctx->shard_level, ctx->d_scalars, ctx->d_scalars + 1, ctx->stream);
+    if (stream_len) *stream_len = (size_t)out_bytes;
+    return BZX_OK;
+}
+
+extern "C" int bzx_shard_assemble_rank(bzx_ctx *ctx, const void *d_packed_r, uint32_t r, void *d_out)
+{
+    if (!ctx || !d_packed_r || !d_out || ((uintptr_t)d_packed_r & 3u) || r >= ctx->shard_world) return BZX_E_PARAM;
+    if (ctx->shard_level == 0) return BZX_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BzxBatch &B = ctx->B;
+    const uint32_t nblk = ctx->shard_total, world = ctx->shard_world;
+    const uint32_t nown = shard_count(nblk, r, world);
+    B.nblk = nblk;
+    B.out = (uint32_t *)d_out;
+    if (nown == 0) return BZX_OK;
+    bzx_launch_pack_layout(B, r, world, nown, ctx->d_scalars + 3, ctx->stream);            // rank r's packed positions
+    bzx_launch_unpack(B, (const uint32_t *)d_packed_r, r, world, nown, grid_for(ctx, nown, 4), ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
     return BZX_OK;
 }
 

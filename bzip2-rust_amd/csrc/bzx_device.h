@@ -36,7 +36,8 @@ struct BzxBlock {
     uint64_t bits;          // size of the block image in bits (header .. last payload bit)
     uint64_t out_bit;       // bit position of the block image in the output buffer
     uint32_t sec_bits[4];   // [0] selectors, [1] coding tables, [2] payload, [3] symbol map
-    uint32_t pad_[2];
+    uint32_t pad_[2];       // [0] copies of every rotation in a periodic block, [1] debug: microseconds in the BWT kernel
+    uint64_t pack_word;     // sharded runs: first 32-bit word of the block image in this rank's packed buffer
 };
 
 // Per-workgroup-slot scratch of the suffix sorter (one slot per resident workgroup).
@@ -55,6 +56,7 @@ struct BzxBatch {
     uint32_t nblk;          // blocks this launch works on: logical j in [0,nblk) -> block blk_first + j*blk_step
     uint32_t blk_first;     // round-robin sharding over GPUs: first = rank, step = world size
     uint32_t blk_step;
+    uint32_t packed;        // emit at blk.pack_word (packed per-rank buffer) instead of blk.out_bit (final stream)
     uint32_t *counters;     // [64] atomic work counters, one per stage kernel (zeroed per batch); [5] = #periodic
     uint32_t *plist;        // [nblk] indices of the blocks flagged periodic by the BWT kernel
     const uint8_t *in;      // block slab buffer (RLE1'd bytes), block b at blk[b].in_off

@@ -103,7 +103,9 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
         const uint16_t *__restrict__ GB = B.gbits + (size_t)b * BZX_SEL_STRIDE;
         uint32_t *out = B.out;
 
-        const uint64_t o_map = d.out_bit + 105;
+        // final stream position, or (sharded runs) the same bit phase inside this rank's packed buffer
+        const uint64_t ob = B.packed ? d.pack_word * 32 + (d.out_bit & 31u) : d.out_bit;
+        const uint64_t o_map = ob + 105;
         const uint64_t o_ng = o_map + d.sec_bits[3];
         const uint64_t o_sel = o_ng + 18;
         const uint64_t o_tab = o_sel + d.sec_bits[0];
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
         // ---- (a) block header, symbol map, nGroups, nSelectors (compress_block.rs:34-48, huffman.rs:209-224)
         if (tid == 0) {
             BitW w;
-            w.init(out, d.out_bit);
+            w.init(out, ob);
             w.put(24, 0x314159u);
             w.put(24, 0x265359u);
             w.put(32, d.crc);
@@ -312,6 +314,73 @@ __global__ void bzx_bits_import_kernel(BzxBatch B, const long long *bits)
         B.blk[b].crc = (uint32_t)((uint64_t)bits[b] >> 32);
     }
 }
+// Packed layout of one rank's blocks (b = first + j*step): every image starts on a word boundary of the packed
+// buffer with the bit phase it has in the final stream, so merging is a word-wise OR.  total[0] = words used.
+__global__ __launch_bounds__(EMIT_NT) void bzx_pack_layout_kernel(BzxBatch B, uint32_t first, uint32_t step,
+                                                                 uint32_t nown, uint64_t *total)
+{
+    __shared__ uint64_t l_wsum[EMIT_NW];
+    __shared__ uint64_t l_carry;
+    const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
+    if (tid == 0) l_carry = 0;
+    __syncthreads();
+    for (uint32_t j0 = 0; j0 < nown; j0 += EMIT_NT) {
+        const uint32_t j = j0 + tid;
+        const uint32_t b = first + j * step;
+        const uint64_t v = j < nown ? (((B.blk[b].out_bit & 31u) + B.blk[b].bits + 31u) >> 5) : 0ull;
+        uint64_t x = v;
+        for (uint32_t dd = 1; dd < 64; dd <<= 1) {
+            const uint64_t y = __shfl_up(x, dd);
+            if (lane >= dd) x += y;
+        }
+        if (lane == 63) l_wsum[wave] = x;
+        const uint64_t carry = l_carry;
+        __syncthreads();
+        uint64_t pre = 0, tot = 0;
+        for (uint32_t i = 0; i < EMIT_NW; i++) {
+            if (i < wave) pre += l_wsum[i];
+            tot += l_wsum[i];
+        }
+        if (j < nown) B.blk[b].pack_word = carry + pre + x - v;
+        __syncthreads();
+        if (tid == 0) l_carry = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) total[0] = l_carry;
+}
+
+// Merge one rank's packed buffer into the final stream: interior words are owned by one block, the first and
+// last word of an image may be shared with its neighbours and are OR-ed into the zeroed buffer.
+__global__ __launch_bounds__(256) void bzx_unpack_kernel(BzxBatch B, const uint32_t *__restrict__ packed, uint32_t first,
+                                                        uint32_t step, uint32_t nown)
+{
+    for (uint32_t j = blockIdx.x; j < nown; j += gridDim.x) {
+        const BzxBlock d = B.blk[first + j * step];
+        const uint64_t nw = ((d.out_bit & 31u) + d.bits + 31u) >> 5;
+        const uint32_t *src = packed + d.pack_word;
+        uint32_t *dst = B.out + (d.out_bit >> 5);
+        for (uint64_t w = threadIdx.x; w < nw; w += blockDim.x) {
+            const uint32_t v = src[w];
+            if (w == 0 || w + 1 == nw) {
+                if (v) atomicOr(&dst[w], v);
+            } else {
+                dst[w] = v;
+            }
+        }
+    }
+}
+
+void bzx_launch_pack_layout(const BzxBatch &B, uint32_t first, uint32_t step, uint32_t nown, uint64_t *d_total,
+                            hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_pack_layout_kernel, dim3(1), dim3(EMIT_NT), 0, stream, B, first, step, nown, d_total);
+}
+void bzx_launch_unpack(const BzxBatch &B, const uint32_t *packed, uint32_t first, uint32_t step, uint32_t nown,
+                       uint32_t grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_unpack_kernel, dim3(grid), dim3(256), 0, stream, B, packed, first, step, nown);
+}
+
 void bzx_launch_bits_export(const BzxBatch &B, long long *bits, hipStream_t stream)
 {
     hipLaunchKernelGGL(bzx_bits_export_kernel, dim3(64), dim3(256), 0, stream, B, bits);

@@ -110,15 +110,22 @@ int bzx_compress_buffer(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level,
  * caller (one process per GPU) exchanges 8 bytes per block between the two calls:
  *   1. bzx_shard_prepare: split the whole input (block boundaries are a serial dependency over the
  *      stream, so every rank derives them from its copy of the raw bytes), run BWT/MTF/Huffman on this
- *      rank's blocks, write their sizes in bits to d_bits[i] (int64, device; other entries untouched).
+ *      rank's blocks, write size-in-bits | crc << 32 of each to d_bits[i] (int64, device; other entries untouched).
  *   2. caller: all-reduce(sum) d_bits over the ranks.
- *   3. bzx_shard_emit: lay out the whole stream from all sizes and emit this rank's blocks at their final
- *      bit positions into d_out (zero elsewhere; rank 0 also writes "BZh<level>" and the footer).
- *   4. caller: reduce(sum) of d_out[0..out_len) to rank 0 == the finished .bz2 (bit ranges are disjoint).
+ *   3. bzx_shard_emit_packed: lay out the whole stream from all sizes, emit this rank's block images back to
+ *      back into d_packed (each on a 32-bit word boundary, with the bit phase it has in the final stream).
+ *   4. caller: gather the packed buffers to one rank (each compressed byte crosses xGMI once).
+ *   5. on that rank: bzx_shard_assemble_begin (zeroed stream + "BZh<level>" + footer + combined CRC), then
+ *      bzx_shard_assemble_rank once per rank: word-wise OR of the images into their final positions.
  */
 int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, int level, uint32_t rank, uint32_t world,
                       uint32_t *nblk_total, long long *d_bits, size_t bits_cap);
-int bzx_shard_emit(bzx_ctx *ctx, const long long *d_bits_all, void *d_out, size_t cap, size_t *out_len);
+int bzx_shard_emit_packed(bzx_ctx *ctx, const long long *d_bits_all, void *d_packed, size_t cap, size_t *packed_len,
+                          size_t *stream_len);
+int bzx_shard_assemble_begin(bzx_ctx *ctx, void *d_out, size_t cap, size_t *stream_len);
+int bzx_shard_assemble_rank(bzx_ctx *ctx, const void *d_packed_r, uint32_t r, void *d_out);
+/* bzx_shard_assemble_* only enqueue work on the context's stream; wait for it here (or on the caller's stream). */
+int bzx_ctx_sync(bzx_ctx *ctx);
 
 /* Per-call telemetry of the last bzx_compress_device/_buffer/_blocks call. */
 typedef struct {

@@ -1,6 +1,6 @@
 """Worker of tests/test_shard_gloo.py: one rank of the round-robin block sharding over gloo.
-Runs the REAL C ABI (bzx_shard_prepare / bzx_shard_emit) through the CPU kernel emulator (tests/emu), with
-CPU tensors standing in for HBM, so the N>1 control flow is exercised without GPUs."""
+Runs the REAL C ABI (bzx_shard_prepare / bzx_shard_emit_packed / bzx_shard_assemble_*) through the CPU kernel
+emulator (tests/emu), with CPU tensors standing in for HBM, so the N>1 control flow is exercised without GPUs."""
 import bz2
 import ctypes as C
 import os
@@ -29,7 +29,10 @@ def main():
     L = lib.lib
     L.bzx_shard_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32,
                                     C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
-    L.bzx_shard_emit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.bzx_shard_emit_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_size_t)]
+    L.bzx_shard_assemble_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.bzx_shard_assemble_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     bits = torch.zeros(64, dtype=torch.int64)
     nblk = C.c_uint32()
     lib._check(L.bzx_shard_prepare(lib.ctx, raw.ctypes.data + off, data.nbytes, level, rank, world, C.byref(nblk),
@@ -43,14 +46,24 @@ def main():
     assert bool((owners[:nblk.value] == 1).all()), owners
     assert all(int(mine[b]) != 0 for b in range(rank, nblk.value, world))
     cap = data.nbytes + 65536
-    out = torch.zeros(cap // 4, dtype=torch.int32)
-    ol = C.c_size_t()
-    lib._check(L.bzx_shard_emit(lib.ctx, bits.data_ptr(), out.data_ptr(), cap, C.byref(ol)))
-    n4 = (ol.value + 3) // 4
-    part = out[:n4].clone()
-    dist.reduce(part, dst=0)          # disjoint bit ranges: sum == OR
+    packed = torch.zeros(cap // 4, dtype=torch.int32)
+    pl, sl = C.c_size_t(), C.c_size_t()
+    lib._check(L.bzx_shard_emit_packed(lib.ctx, bits.data_ptr(), packed.data_ptr(), cap, C.byref(pl), C.byref(sl)))
+    assert pl.value % 4 == 0
+    pmax = torch.tensor([pl.value], dtype=torch.int64)
+    dist.all_reduce(pmax, op=dist.ReduceOp.MAX)
+    n4 = int(pmax.item()) // 4
+    parts = [torch.zeros(n4, dtype=torch.int32) for _ in range(world)] if rank == 0 else None
+    dist.gather(packed[:n4].contiguous(), parts, dst=0)      # every compressed byte travels once
     if rank == 0:
-        z = part.numpy().tobytes()[:ol.value]
+        out = torch.full((cap // 4,), -1, dtype=torch.int32)   # assemble_begin must clear what it uses
+        ol = C.c_size_t()
+        lib._check(L.bzx_shard_assemble_begin(lib.ctx, out.data_ptr(), cap, C.byref(ol)))
+        assert ol.value == sl.value
+        for r in range(world):
+            lib._check(L.bzx_shard_assemble_rank(lib.ctx, parts[r].data_ptr(), r, out.data_ptr()))
+        lib._check(L.bzx_ctx_sync(lib.ctx))
+        z = out.numpy().tobytes()[:ol.value]
         want = bz2.compress(data.tobytes(), level)
         assert z == want, (len(z), len(want))
         assert nblk.value == 3

@@ -165,24 +165,32 @@ def test_random_and_zero_heavy_inputs(bzx, oracle):
 
 
 def test_shard_entry_points_single_rank(bzx, oracle):
-    """bzx_shard_prepare / bzx_shard_emit with world size 1 on the device: same stream as libbz2.
+    """bzx_shard_prepare / bzx_shard_emit_packed / bzx_shard_assemble_*  with world size 1 on the
+    device: same stream as libbz2.
     (World size 2 is covered on CPU over gloo in tests/test_shard_gloo.py.)"""
     import ctypes as C
     import torch
     L = bzx.lib
     L.bzx_shard_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32,
                                     C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
-    L.bzx_shard_emit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.bzx_shard_emit_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_size_t)]
+    L.bzx_shard_assemble_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.bzx_shard_assemble_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     data = oracle.synthtext(5_000_000) + b"\0" * 70000 + oracle.randbytes(300000)
     d_raw = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
     bits = torch.zeros(64, dtype=torch.int64, device="cuda")
     cap = len(data) + len(data) // 4 + 65536
-    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    d_out = torch.full((cap,), 255, dtype=torch.uint8, device="cuda")
+    d_packed = torch.full((cap,), 255, dtype=torch.uint8, device="cuda")
     nblk = C.c_uint32()
     torch.cuda.synchronize()
     bzx._check(L.bzx_shard_prepare(bzx.ctx, d_raw.data_ptr(), len(data), 9, 0, 1, C.byref(nblk), bits.data_ptr(), 64))
-    ol = C.c_size_t()
-    bzx._check(L.bzx_shard_emit(bzx.ctx, bits.data_ptr(), d_out.data_ptr(), cap, C.byref(ol)))
+    pl, ol = C.c_size_t(), C.c_size_t()
+    bzx._check(L.bzx_shard_emit_packed(bzx.ctx, bits.data_ptr(), d_packed.data_ptr(), cap, C.byref(pl), C.byref(ol)))
+    bzx._check(L.bzx_shard_assemble_begin(bzx.ctx, d_out.data_ptr(), cap, None))
+    bzx._check(L.bzx_shard_assemble_rank(bzx.ctx, d_packed.data_ptr(), 0, d_out.data_ptr()))
+    bzx._check(L.bzx_ctx_sync(bzx.ctx))
     torch.cuda.synchronize()
     out = d_out[:ol.value].cpu().numpy().tobytes()
     assert nblk.value == 6 and out == bz2.compress(data, 9)

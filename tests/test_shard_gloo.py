@@ -1,5 +1,6 @@
 """CPU test (-m "not gpu") of the N>1 path: world size 2 over gloo on 127.0.0.1.
-Two processes run bzx_shard_prepare -> all_reduce(block sizes) -> bzx_shard_emit -> reduce(sum) exactly as
+Two processes run bzx_shard_prepare -> all_reduce(block sizes) -> bzx_shard_emit_packed -> gather ->
+bzx_shard_assemble_begin/_rank on rank 0 exactly as
 bench.py does with RCCL, but through the kernel emulator (tests/emu) with CPU tensors; rank 0's result must be
 byte-identical to libbz2's stream of the whole input."""
 import os
