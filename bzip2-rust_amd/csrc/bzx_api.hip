@@ -807,6 +807,13 @@ extern "C" int bzx_shard_assemble_rank(bzx_ctx *ctx, const void *d_packed_r, uin
 }
 
 // Debug helper (not in include/bzx.h): enable/read the BWT kernel's phase timers (100 MHz wall-clock ticks summed over blocks).
+extern "C" int bzx_dbg_set_stop(bzx_ctx *ctx, uint32_t k)
+{
+    if (!ctx) return BZX_E_PARAM;
+    ctx->B.dbg_stop = k;
+    return BZX_OK;
+}
+
 extern "C" int bzx_dbg_phase_timers(bzx_ctx *ctx, int enable, unsigned long long out[64])
 {
     if (!ctx) return BZX_E_PARAM;

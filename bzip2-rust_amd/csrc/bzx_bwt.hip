@@ -45,12 +45,19 @@
 #define MODE_TEXT 1
 #define MODE_RANK 2
 #define TEXT_ROUNDS 4
+// TEXT records of a group that the symbol-wise splitter gave up on (deep repeats inside a large group): the
+// group is left alone by the tile rounds and resolved by prefix doubling (RANK rounds) afterwards
+#define TXT_FROZEN (1ull << 38)
 
 __shared__ uint32_t s_hist[5][256];
 __shared__ uint32_t s_base[256];
 __shared__ uint32_t s_wcnt[2][SORT_NW * 256];
 __shared__ uint32_t s_scratch[2 * SORT_NW];
 #define RADIX_STAGED 1
+#define RADIX_LDS_MATCH 1
+#if RADIX_LDS_MATCH
+__shared__ uint64_t s_wmask[SORT_NW][256];      // per wave, per digit: lanes holding that digit (transient)
+#endif
 #if RADIX_STAGED
 __shared__ uint64_t s_stage[SORT_NT * SORT_E];   // one tile of records, grouped by digit, for coalesced write-out
 __shared__ uint32_t s_lbase[256];                // tile-local start of every digit's run
@@ -106,6 +113,10 @@ __device__ __forceinline__ uint32_t pack_symbols32(uint64_t w, uint32_t bits, ui
 #pragma unroll
     for (int j = 0; j < 8; j++)
         if ((uint32_t)j < ksym) key = (key << bits) | sy[j];
+    // the bits left over (4 of 32 for a 7-bit alphabet) hold the top bits of the next symbol: still order
+    // preserving, and groups that tie on the key still agree on ksym whole symbols
+    const uint32_t spare = 32u - ksym * bits;
+    if (ksym < 8 && spare) key = (key << spare) | (sy[ksym] >> (bits - spare));
     return key;
 }
 
@@ -119,8 +130,21 @@ __device__ __forceinline__ uint64_t init_record(const uint8_t *__restrict__ T, u
 }
 
 // One stable LSD pass: src[0..m) -> dst by the 8-bit digit at `shift`; hist = digit histogram (LDS).
-// FROM_TEXT: the source records are generated on the fly from the block bytes (first pass of the initial sort).
-template <bool FROM_TEXT>
+// SRC_TEXT: the source records are generated on the fly from the block bytes (first pass of the initial sort).
+// SRC_SA:   the source records are [SA[j]:20 @20 | j:20 @0] generated from the suffix array (ISA build).
+#define SRC_REC 0
+#define SRC_TEXT 1
+#define SRC_SA 2
+template <int SRC>
+__device__ __forceinline__ uint64_t radix_source(const uint64_t *__restrict__ src, uint32_t idx, uint32_t m,
+                                                 const uint8_t *__restrict__ T, uint32_t bits, uint32_t ksym)
+{
+    if (SRC == SRC_TEXT) return init_record(T, m, idx, bits, ksym);
+    if (SRC == SRC_SA) return ((uint64_t)((const uint32_t *)T)[idx] << 20) | (uint64_t)idx;
+    return src[idx];
+}
+
+template <int SRC>
 __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint32_t m, int shift,
                            const uint32_t *hist, const uint8_t *__restrict__ T = nullptr, uint32_t bits = 8,
                            uint32_t ksym = 4)
@@ -131,6 +155,9 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
     const uint32_t ex = bzx_block_excl_sum<SORT_NT>(v, s_scratch, tot);
     if (tid < 256) s_base[tid] = ex;
     for (uint32_t i = tid; i < SORT_NW * 256; i += SORT_NT) s_wcnt[0][i] = 0;
+#if RADIX_LDS_MATCH
+    for (uint32_t i = tid; i < SORT_NW * 256; i += SORT_NT) (&s_wmask[0][0])[i] = 0;
+#endif
     __syncthreads();
 
     int cur = 0;
@@ -143,7 +170,7 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
 #pragma unroll
         for (int e = 0; e < SORT_E; e++) {
             const uint32_t idx = wbase + e * 64 + lane;
-            nxt[e] = idx < m ? (FROM_TEXT ? init_record(T, m, idx, bits, ksym) : src[idx]) : 0ull;
+            nxt[e] = idx < m ? radix_source<SRC>(src, idx, m, T, bits, ksym) : 0ull;
         }
     }
     for (uint32_t t0 = 0; t0 < m; t0 += SORT_NT * SORT_E) {
@@ -157,15 +184,33 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
 #pragma unroll
             for (int e = 0; e < SORT_E; e++) {
                 const uint32_t idx = nbase + e * 64 + lane;
-                nxt[e] = idx < m ? (FROM_TEXT ? init_record(T, m, idx, bits, ksym) : src[idx]) : 0ull;
+                nxt[e] = idx < m ? radix_source<SRC>(src, idx, m, T, bits, ksym) : 0ull;
             }
         }
         uint32_t *wc = &s_wcnt[cur][wave * 256];
+#if RADIX_LDS_MATCH
+        uint64_t *wm = &s_wmask[wave][0];
+#endif
 #pragma unroll
         for (int e = 0; e < SORT_E; e++) {
             const uint32_t idx = wbase + e * 64 + lane;
             const bool valid = idx < m;
             const uint32_t d = (uint32_t)(rec[e] >> shift) & 255u;
+#if RADIX_LDS_MATCH
+            // peers = lanes of this wave with my digit, collected by OR-ing lane bits into a per-wave, per-digit
+            // 64-bit LDS word (LDS executes a wave's instructions in order); the leader clears the word again
+            if (valid) atomicOr((unsigned long long *)&wm[d], 1ull << lane);
+            bzx_wave_sync();
+            const uint64_t peers = valid ? ((volatile uint64_t *)wm)[d] : 0ull;
+            uint32_t old = valid ? ((volatile uint32_t *)wc)[d] : 0u;
+            bzx_wave_sync();
+            const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+            if (valid && (peers & lt_mask) == 0) {
+                wc[d] = old + (uint32_t)__popcll(peers);
+                wm[d] = 0;
+            }
+            bzx_wave_sync();
+#else
             const uint64_t peers = bzx_match_any(d, 8, valid);
             const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
             const int leader = __ffsll((unsigned long long)peers) - 1;
@@ -175,6 +220,7 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
                 wc[d] = old + (uint32_t)__popcll(peers);
             }
             old = __shfl(old, leader & 63);
+#endif
             off[e] = old + rank;
             dig[e] = d;
         }
@@ -309,9 +355,10 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
             if (k < m) {
                 if (f[j]) ks = k + 1;
                 const uint32_t kstart = ks - 1;
-                if (k - kstart + 1 > my_maxgrp) my_maxgrp = k - kstart + 1;
-                const uint32_t newrank = INITIAL ? kstart : S[kstart];
                 const uint64_t rec = r[j + 1];
+                const bool frozen = (MODE == MODE_TEXT) && (rec & TXT_FROZEN);
+                if (!frozen && k - kstart + 1 > my_maxgrp) my_maxgrp = k - kstart + 1;
+                const uint32_t newrank = INITIAL ? kstart : S[kstart];
                 const uint32_t sa = (uint32_t)(rec >> SA_SHIFT) & 0xFFFFFu;
                 const uint32_t pos = INITIAL ? k : S[k];
                 SA[pos] = sa;
@@ -326,7 +373,8 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
                 if (!(f[j] && f[j + 1])) {
                     Unew[o] = (MODE == MODE_RANK)
                                   ? (((uint64_t)newrank << G_SHIFT) | ((uint64_t)sa << RNK_SA_SHIFT))
-                                  : (((uint64_t)newrank << G_SHIFT) | ((uint64_t)sa << TXT_SA_SHIFT) | (rec & 0xFFull));
+                                  : (((uint64_t)newrank << G_SHIFT) | ((uint64_t)sa << TXT_SA_SHIFT) | (rec & 0xFFull) |
+                                     (frozen ? TXT_FROZEN : 0ull));
                     Snew[o] = pos;
                     o++;
                 }
@@ -343,6 +391,33 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
     const uint32_t res = s_bcast[2];
     __syncthreads();
     return res;
+}
+
+// ISA[SA[j]] = j for every sorted position j (a permutation inversion).  A direct scatter writes 4 bytes into
+// a different cache line per store; instead one stable radix pass groups the pairs (SA[j], j) by SA[j] >> 12
+// (every value occurs once, so digit d owns exactly the output range [4096 d, 4096 (d+1)) and no histogram pass
+// is needed), then each 8192-entry window of ISA is assembled in LDS and written out coalesced.
+__device__ __attribute__((noinline)) void isa_build(const uint32_t *__restrict__ SA, uint32_t *__restrict__ ISA,
+                                                    uint64_t *__restrict__ tmp, uint32_t n)
+{
+    const uint32_t tid = threadIdx.x;
+    if (tid < 256) {
+        const uint32_t lo = tid << 12;
+        s_hist[0][tid] = lo >= n ? 0u : (n - lo < 4096u ? n - lo : 4096u);
+    }
+    __syncthreads();
+    radix_pass<SRC_SA>(nullptr, tmp, n, 32, s_hist[0], (const uint8_t *)SA);
+    uint32_t *win = (uint32_t *)s_stage;                  // 8192 ranks
+    for (uint32_t w0 = 0; w0 < n; w0 += 8192) {
+        const uint32_t cnt = n - w0 < 8192u ? n - w0 : 8192u;
+        for (uint32_t t = tid; t < cnt; t += SORT_NT) {
+            const uint64_t rec = tmp[w0 + t];
+            win[(uint32_t)(rec >> 20) & 8191u] = (uint32_t)rec & 0xFFFFFu;
+        }
+        __syncthreads();
+        for (uint32_t t = tid; t < cnt; t += SORT_NT) ISA[w0 + t] = win[t];
+        __syncthreads();
+    }
 }
 
 // key2 = rank of the rotation h positions further on; fills the five digit histograms.
@@ -443,11 +518,12 @@ template <bool TEXT, int SEG_PER_LANE> __device__ __forceinline__ void bitonic_t
 }
 
 // first group start at or after r0 (groups have <= 64*SEG_PER_LANE members), or m
-template <int SEG_PER_LANE>
+template <bool TEXT, int SEG_PER_LANE>
 __device__ __forceinline__ uint32_t seg_align(const uint64_t *__restrict__ U, uint32_t m, uint32_t r0, uint32_t lane)
 {
     if (r0 == 0) return 0;
     if (r0 >= m) return m;
+    if (TEXT && (U[r0] & TXT_FROZEN)) return r0;      // a frozen group may be cut anywhere: the round skips it
     uint32_t best = 0xffffffffu;
 #pragma unroll
     for (int j = 0; j < SEG_PER_LANE; j++) {
@@ -475,8 +551,8 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
     constexpr uint32_t SEG_TILE = 64 * SEG_PER_LANE;
     const uint32_t lane = bzx_lane(), wave = bzx_wave();
     const uint32_t share = (m + SORT_NW - 1) / SORT_NW;
-    uint32_t a = seg_align<SEG_PER_LANE>(U, m, wave * share < m ? wave * share : m, lane);
-    const uint32_t end = seg_align<SEG_PER_LANE>(U, m, (wave + 1) * share < m ? (wave + 1) * share : m, lane);
+    uint32_t a = seg_align<TEXT, SEG_PER_LANE>(U, m, wave * share < m ? wave * share : m, lane);
+    const uint32_t end = seg_align<TEXT, SEG_PER_LANE>(U, m, (wave + 1) * share < m ? (wave + 1) * share : m, lane);
     const uint32_t hmod = h % n;
     while (a < end) {
         const uint32_t lim = (end - a < SEG_TILE) ? end : a + SEG_TILE;     // tile may reach at most lim
@@ -487,26 +563,48 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
             v[j].rec = i < lim ? U[i] : ~0ull;
             v[j].key = 0;
         }
-        // b = last group boundary in (a, lim]  (lim == end is a boundary)
+        if (TEXT) {
+            // frozen group at the tile start: skip to its end (the first boundary in the tile) without sorting
+            const uint64_t first = __shfl(v[0].rec, 0);
+            if (first & TXT_FROZEN) {
+                const uint64_t after = __shfl_down(v[0].rec, 1);
+                uint32_t fb = lim;
+#pragma unroll
+                for (int j = SEG_PER_LANE - 1; j >= 0; j--) {
+                    const uint32_t i = a + lane * SEG_PER_LANE + (uint32_t)j + 1;
+                    const uint64_t nx = (j + 1 < SEG_PER_LANE) ? v[(j + 1) & (SEG_PER_LANE - 1)].rec : after;
+                    if (i < lim && (nx >> G_SHIFT) != (v[j].rec >> G_SHIFT)) fb = i;
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    const uint32_t o = __shfl_xor(fb, d);
+                    fb = o < fb ? o : fb;
+                }
+                a = fb;
+                continue;
+            }
+        }
+        // b = last group boundary in (a, lim]  (lim == end is a boundary, unless a frozen group was cut there)
+        const bool tail_frozen = TEXT && lim == end && (U[lim - 1] & TXT_FROZEN);
         uint32_t b = lim;
-        if (lim != end) {
+        if (lim != end || tail_frozen) {
             uint64_t after = __shfl_down(v[0].rec, 1);      // first record of the next lane
-            if (lane == 63) after = U[lim];                 // lim < end <= m
+            if (lane == 63) after = lim < m ? U[lim] : ~0ull;
             uint32_t best = 0;
 #pragma unroll
             for (int j = 0; j < SEG_PER_LANE; j++) {
                 const uint32_t i = a + lane * SEG_PER_LANE + (uint32_t)j + 1;       // candidate boundary index
                 const uint64_t cur = v[j].rec;
                 const uint64_t nx = (j + 1 < SEG_PER_LANE) ? v[(j + 1) & (SEG_PER_LANE - 1)].rec : after;
-                if (i <= lim && (nx >> G_SHIFT) != (cur >> G_SHIFT)) best = i;
+                if ((i < lim || (i == lim && !tail_frozen)) && (nx >> G_SHIFT) != (cur >> G_SHIFT)) best = i;
             }
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) {
                 const uint32_t o = __shfl_xor(best, d);
                 best = o > best ? o : best;
             }
-            b = best;       // > a because the group starting at a has <= SEG_T members
-            if (b <= a) b = lim;   // defensive: never stall (cannot happen when the size bound holds)
+            b = best;       // > a: the group starting at a is not frozen, so it has <= SEG_TILE members
+            if (b <= a) b = lim;   // defensive: never stall
         }
         // secondary keys for the records of this tile, mask the rest
 #pragma unroll
@@ -516,13 +614,24 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
                 if (TEXT) {
                     uint32_t p = ((uint32_t)(v[j].rec >> TXT_SA_SHIFT) & 0xFFFFFu) + hmod;
                     if (p >= n) p -= n;
+#ifdef BZX_EXP_NOGATHER
+                    const uint64_t w0 = (uint64_t)p * 0x9E3779B97F4A7C15ull;
+#else
                     const uint64_t w0 = text_key8(T, n, p);
+#endif
                     uint64_t w1 = 0;
                     if (csym > 8) {
                         uint32_t p2 = p + 8;
                         while (p2 >= n) p2 -= n;
+#ifdef BZX_EXP_NOGATHER
+                        w1 = (uint64_t)p2 * 0xC2B2AE3D27D4EB4Full;
+#else
                         w1 = text_key8(T, n, p2);
+#endif
                     }
+#ifdef BZX_EXP_NOPACK
+                    v[j].key = w0 ^ (w1 >> 3);
+#else
                     uint32_t sy[16];
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
@@ -534,6 +643,7 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
                     for (int q = 0; q < 16; q++)
                         if ((uint32_t)q < csym) key = (key << bits) | (uint64_t)sy[q];
                     v[j].key = key;
+#endif
                     v[j].rec &= ~(0x3FFull << TXT_KEY_SHIFT);     // clear the tile-local slot of the last round
                 } else {
                     uint32_t p = ((uint32_t)(v[j].rec >> RNK_SA_SHIFT) & 0xFFFFFu) + hmod;
@@ -545,7 +655,9 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
                 v[j].key = ~0ull;
             }
         }
+#ifndef BZX_EXP_NOSORT
         bitonic_tile<TEXT, SEG_PER_LANE>(v, lane);
+#endif
         if (TEXT) {
             // tile-local index of the first member of every new (g, key) group -> record bits 28..37
             SegRec pl;                                     // last element of the previous lane
@@ -591,7 +703,7 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
 // still larger than a tile are split again by the following symbol.  Splitting only strengthens the round
 // invariant (all members of a group agree on at least `depth` symbols), so the tile round that follows is
 // unchanged.
-#define BIG_MAX 3000         // big groups per pass (lists live in the ISA array, which TEXT mode does not use)
+#define BIG_MAX 3600         // big groups per pass (lists live in the ISA array, which TEXT mode does not use)
 #define BIG_PASSES 64
 #define BIG_COOP 4096        // groups above this size are split by the whole workgroup, smaller ones by one wave
 __shared__ uint32_t s_big[5];     // [0] groups in the current list, [1] in the next list, [2] overflow flag,
@@ -615,7 +727,7 @@ __device__ __attribute__((noinline)) void big_find(const uint64_t *__restrict__ 
         const bool is_end = (k + 1 == m) || ((uint32_t)(U[k + 1] >> G_SHIFT) != g);
         if (is_end) {
             const uint32_t size = S[k] - g + 1;        // slots of a group are consecutive SA positions
-            if (size > SEG_T_TEXT) {
+            if (size > SEG_T_TEXT && !(rec & TXT_FROZEN)) {
                 const uint32_t idx = atomicAdd(&s_big[0], 1u);
                 atomicAdd(&s_big[3], size);
                 if (idx < BIG_MAX) {
@@ -744,19 +856,26 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
     }
 }
 
-// Splits every group with more than SEG_T_TEXT members.  Returns true when all groups fit a tile afterwards.
-__device__ __attribute__((noinline)) bool big_split(uint64_t *__restrict__ U, uint64_t *__restrict__ Utmp,
-                                                     const uint32_t *__restrict__ S, uint32_t m,
-                                                     uint32_t *__restrict__ scratch, const uint8_t *__restrict__ T,
-                                                     uint32_t n, uint32_t depth)
+// Splits every group with more than SEG_T_TEXT members by single symbols until it fits a tile.  Groups that single
+// symbols separate too slowly (deep repeats: two passes in a row that leave >88 % of the listed rotations in
+// oversized groups, or a work budget of 4 n rotation-passes) are FROZEN: flagged in their records, skipped by the
+// tile rounds and resolved by prefix doubling later.  Returns 0 when every group fits a tile now, else the number
+// of symbols (>= depth) that all frozen groups are known to agree on.
+__device__ __attribute__((noinline)) uint32_t big_split(uint64_t *__restrict__ U, uint64_t *__restrict__ Utmp,
+                                                         const uint32_t *__restrict__ S, uint32_t m,
+                                                         uint32_t *__restrict__ scratch, const uint8_t *__restrict__ T,
+                                                         uint32_t n, uint32_t depth)
 {
     uint32_t *la = scratch, *lb = scratch + 2 * BIG_MAX;
     big_find(U, S, m, la);
-    for (uint32_t pass = 0; pass < BIG_PASSES; pass++) {
+    uint32_t stall = 0, pass = 0;
+    uint64_t work = 0;
+    for (;; pass++) {
         const uint32_t nlist = s_big[0], ovf = s_big[2], before = s_big[3];
         __syncthreads();
-        if (ovf) return false;
-        if (nlist == 0) return true;
+        if (nlist == 0 && !ovf) return 0;
+        work += before;
+        if (ovf || pass >= BIG_PASSES || stall >= 2 || work > 4ull * n) break;
         big_split_pass(U, Utmp, la, nlist, lb, T, n, depth + pass);
         const uint32_t after = s_big[4];
         __syncthreads();
@@ -767,16 +886,26 @@ __device__ __attribute__((noinline)) bool big_split(uint64_t *__restrict__ U, ui
             s_big[4] = 0;
         }
         __syncthreads();
-        // long common prefixes (runs, repeated records): single symbols do not separate them -- when a pass
-        // leaves more than 60 % of the rotations in oversized groups, leave the block to prefix doubling
-        if (after && (uint64_t)after * 10 > (uint64_t)before * 6) return false;
+        stall = ((uint64_t)after * 100 > (uint64_t)before * 88) ? stall + 1 : 0;
         uint32_t *t = la;
         la = lb;
         lb = t;
     }
-    const bool ok = s_big[0] == 0 && s_big[2] == 0;
+    // freeze what is still oversized: the member at offset o of a group (slots are consecutive, so o = S[k] - g)
+    // belongs to a group of more than SEG_T_TEXT rotations iff the record SEG_T_TEXT - o places on has the same g
+    for (uint32_t k = threadIdx.x; k < m; k += SORT_NT) {
+        const uint64_t rec = U[k];
+        if (rec & TXT_FROZEN) continue;
+        const uint32_t g = (uint32_t)(rec >> G_SHIFT), off = S[k] - g;
+        bool big = off >= SEG_T_TEXT;
+        if (!big) {
+            const uint32_t j = k + (SEG_T_TEXT - off);
+            big = j < m && (uint32_t)(U[j] >> G_SHIFT) == g;
+        }
+        if (big) U[k] = rec | TXT_FROZEN;
+    }
     __syncthreads();
-    return ok;
+    return depth + pass;        // every listed group was split by the symbols depth .. depth+pass-1
 }
 
 // diagnostic phase timers (B.dbg != null only in profiling runs): accumulate wall-clock ticks per phase
@@ -841,13 +970,15 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         }
         __syncthreads();
         PHASE_STAMP(0);
+        if (B.dbg_stop == 1) continue;
 
         // ---- I2: four LSD passes over the 32-bit key (record bits 28..59)
-        radix_pass<true>(nullptr, ws.u0, n, TXT_KEY_SHIFT, s_hist[0], T, bits, ksym);
-        radix_pass<false>(ws.u0, ws.u1, n, TXT_KEY_SHIFT + 8, s_hist[1]);
-        radix_pass<false>(ws.u1, ws.u0, n, TXT_KEY_SHIFT + 16, s_hist[2]);
-        radix_pass<false>(ws.u0, ws.u1, n, TXT_KEY_SHIFT + 24, s_hist[3]);
+        radix_pass<SRC_TEXT>(nullptr, ws.u0, n, TXT_KEY_SHIFT, s_hist[0], T, bits, ksym);
+        radix_pass<SRC_REC>(ws.u0, ws.u1, n, TXT_KEY_SHIFT + 8, s_hist[1]);
+        radix_pass<SRC_REC>(ws.u1, ws.u0, n, TXT_KEY_SHIFT + 16, s_hist[2]);
+        radix_pass<SRC_REC>(ws.u0, ws.u1, n, TXT_KEY_SHIFT + 24, s_hist[3]);
         PHASE_STAMP(1);
+        if (B.dbg_stop == 2) continue;
 
         // ---- R: ranks by the first four bytes
         uint64_t *ua = ws.u0, *ub = ws.u1;      // ua: current compacted records, ub: the other buffer
@@ -855,19 +986,22 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         uint32_t *orig_out = &B.blk[b].orig_ptr;
         uint32_t m = rerank<MODE_INIT>(ws.u1, nullptr, n, ua, sa_cur, ws.isa, ws.sa, L, orig_out, T, n);
         PHASE_STAMP(2);
+        if (B.dbg_stop == 3) continue;
 
         // ---- TEXT rounds: csym more symbols per round; oversized groups are split by single symbols first
-        uint32_t depth = ksym, round = 0;
+        uint32_t depth = ksym, round = 0, frozen_depth = 0xffffffffu;
         while (m > 0 && depth < n && round < TEXT_ROUNDS) {
             const uint32_t maxgrp = s_bcast[3];
             __syncthreads();
             if (maxgrp > SEG_T_TEXT) {
-                const bool ok = big_split(ua, ub, sa_cur, m, ws.isa, T, n, depth);
+                const uint32_t fr = big_split(ua, ub, sa_cur, m, ws.isa, T, n, depth);
                 PHASE_STAMP(10 + (round < 7 ? round : 7) * 3);
-                if (!ok) break;
+                if (fr && fr < frozen_depth) frozen_depth = fr;           // frozen groups agree on >= fr symbols
             }
+            if (B.dbg_stop == 4) break;
             seg_sort_round<true, 4>(ua, m, nullptr, T, n, depth, bits, csym);
             PHASE_STAMP(8 + (round < 7 ? round : 7) * 3);
+            if (B.dbg_stop == 5) break;
             const uint32_t m_before = m;
             m = rerank<MODE_TEXT>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out, T, n);
             PHASE_STAMP(9 + (round < 7 ? round : 7) * 3);
@@ -875,15 +1009,17 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
             uint32_t *ts = sa_cur; sa_cur = sa_alt; sa_alt = ts;
             depth += csym;
             round++;
+            if (B.dbg_stop == 6) break;
             // long repeats: when a round resolves less than 30 % of what it was given, doubling is cheaper
             if (round >= 2 && (uint64_t)m * 10 > (uint64_t)m_before * 7) break;
+            if ((uint64_t)m * 10 > (uint64_t)m_before * 9) break;      // (almost) nothing but deep repeats / frozen groups left
         }
         __syncthreads();
+        if (B.dbg_stop) continue;
 
         // ---- RANK rounds (deep repeats): build ISA once, then prefix doubling on ranks
         if (m > 0 && depth < n) {
-            for (uint32_t j = tid; j < n; j += SORT_NT) ws.isa[ws.sa[j]] = j;       // resolved rotations: final rank
-            __syncthreads();
+            isa_build(ws.sa, ws.isa, ub, n);                                        // resolved rotations: final rank
             for (uint32_t k = tid; k < m; k += SORT_NT) {                           // unresolved: group start
                 const uint64_t rec = ua[k];
                 const uint32_t sa = (uint32_t)(rec >> TXT_SA_SHIFT) & 0xFFFFFu;
@@ -893,10 +1029,18 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
             }
             __syncthreads();
             PHASE_STAMP(5);
-            uint32_t h = depth;
+            // every unresolved group agrees on at least h symbols (frozen groups stopped at an earlier depth)
+            uint32_t h = depth < frozen_depth ? depth : frozen_depth, rround = 0;
+            bool force_global = frozen_depth != 0xffffffffu;     // the last TEXT rerank did not measure frozen groups
             while (m > 0 && h < n) {
-                const uint32_t maxgrp = s_bcast[3];
+                const uint32_t maxgrp = force_global ? 0xFFFFFu : s_bcast[3];
+                force_global = false;
                 __syncthreads();
+                if (B.dbg && tid == 0) {       // diagnostics: unresolved rotations / largest group entering RANK round r
+                    atomicAdd(&B.dbg[52 + (rround < 5 ? rround : 5) * 2], (unsigned long long)m);
+                    atomicAdd(&B.dbg[53 + (rround < 5 ? rround : 5) * 2], (unsigned long long)maxgrp);
+                }
+                rround++;
                 if (maxgrp <= SEG_T) {
                     seg_sort_round<false, 8>(ua, m, ws.isa, T, n, h);
                     m = rerank<MODE_RANK>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out, T, n);
@@ -904,11 +1048,11 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
                 } else {
                     gather_keys(ua, m, ws.isa, n, h);
                     // five passes: ua -> ub -> ua -> ub -> ua -> ub
-                    radix_pass<false>(ua, ub, m, RNK_KEY_SHIFT, s_hist[0]);
-                    radix_pass<false>(ub, ua, m, RNK_KEY_SHIFT + 8, s_hist[1]);
-                    radix_pass<false>(ua, ub, m, RNK_KEY_SHIFT + 16, s_hist[2]);
-                    radix_pass<false>(ub, ua, m, RNK_KEY_SHIFT + 24, s_hist[3]);
-                    radix_pass<false>(ua, ub, m, RNK_KEY_SHIFT + 32, s_hist[4]);
+                    radix_pass<SRC_REC>(ua, ub, m, RNK_KEY_SHIFT, s_hist[0]);
+                    radix_pass<SRC_REC>(ub, ua, m, RNK_KEY_SHIFT + 8, s_hist[1]);
+                    radix_pass<SRC_REC>(ua, ub, m, RNK_KEY_SHIFT + 16, s_hist[2]);
+                    radix_pass<SRC_REC>(ub, ua, m, RNK_KEY_SHIFT + 24, s_hist[3]);
+                    radix_pass<SRC_REC>(ua, ub, m, RNK_KEY_SHIFT + 32, s_hist[4]);
                     m = rerank<MODE_RANK>(ub, sa_cur, m, ua, sa_alt, ws.isa, ws.sa, L, orig_out, T, n);
                 }
                 uint32_t *ts = sa_cur; sa_cur = sa_alt; sa_alt = ts;

@@ -74,6 +74,7 @@ struct BzxBatch {
     uint32_t *out;          // output bit buffer (zeroed), big-endian bit order
     BzxSortWs *sort_ws;     // [n_slots]
     uint32_t n_slots;
+    uint32_t dbg_stop;       // diagnostics only: leave the BWT kernel after phase k (0 = run everything)
     unsigned long long *dbg; // optional [64] phase timers (100 MHz ticks), null in production
 };
 

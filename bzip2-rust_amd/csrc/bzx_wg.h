@@ -19,7 +19,11 @@
 #ifdef BZX_HIP_EMU
 #define bzx_wave_sync() hipemu::wave_sync()
 #else
-#define bzx_wave_sync() __builtin_amdgcn_wave_barrier()
+#define bzx_wave_sync()                                      \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+    } while (0)
 #endif
 
 __device__ __forceinline__ uint32_t bzx_lane() { return threadIdx.x & 63u; }

@@ -1,5 +1,5 @@
 """Ad-hoc GPU probe: per-block time in the BWT kernel on real data; dumps the slowest block for offline analysis."""
-import sys, glob, ctypes as C
+import os, sys, glob, ctypes as C
 sys.path.insert(0, "tests")
 import numpy as np, torch
 from bzx_ctypes import *
@@ -7,10 +7,14 @@ lib = BzxLib(max_blocks=400); L = lib.lib
 L.bzx_dbg_phase_timers.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 L.bzx_dbg_block_times.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
 def collect(patterns, limit):
-    out = bytearray()
+    out = bytearray(); seen = set()
     for pat in patterns:
         for f in sorted(glob.glob(pat, recursive=True)):
-            try: out += open(f, "rb").read()
+            try:
+                rp = os.path.realpath(f)
+                if rp in seen or os.path.isdir(rp): continue
+                seen.add(rp)
+                out += open(rp, "rb").read()
             except Exception: pass
             if len(out) >= limit: return bytes(out[:limit])
     return bytes(out)

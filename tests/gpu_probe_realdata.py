@@ -4,11 +4,15 @@ sys.path.insert(0, "tests")
 from bzx_ctypes import *
 lib = BzxLib(max_blocks=400)
 def collect(patterns, limit):
-    out = bytearray()
+    out = bytearray(); seen = set()
     for pat in patterns:
         for f in sorted(glob.glob(pat, recursive=True)):
             try:
-                out += open(f, "rb").read()
+                rp = os.path.realpath(f)
+                if rp in seen or os.path.isdir(rp):
+                    continue
+                seen.add(rp)
+                out += open(rp, "rb").read()
             except Exception:
                 pass
             if len(out) >= limit:
