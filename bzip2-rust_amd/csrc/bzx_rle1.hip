@@ -489,14 +489,25 @@ __device__ uint32_t gf_xpow8(uint64_t nbytes)
 }
 
 #define CRC_NT 1024
+#define CRC_SUB 64                         // bytes per lane per tile
+#define CRC_TILE (CRC_NT * CRC_SUB)        // 64 KiB
+#define CRC_PITCH 72                       // LDS row pitch of a lane's 64 bytes (8-byte aligned, spreads banks)
+
+// One workgroup per block.  The block's raw bytes are walked in 64 KiB tiles that END at the block end (the
+// first tile is padded with virtual leading zero bytes, which do not change a zero-initialised CRC register):
+// coalesced 16-byte loads -> LDS -> every lane runs slicing-by-8 over its own 64 contiguous bytes.  A lane keeps
+// one running register across tiles (Horner step: R = R * x^(8*65536) + r, the multiplication by table), so the
+// GF(2) combination of the 1024 lanes happens once per block: D = sum_t R_t * x^(8*64*(1023-t)), and
+// crc = ~(0xffffffff * x^(8*total) + D).
 __global__ __launch_bounds__(CRC_NT) void bzx_rl_crc_kernel(const uint8_t *__restrict__ raw, BzxSplitWs ws,
                                                             BzxBlock *__restrict__ blk, uint32_t own_first,
                                                             uint32_t own_step)
 {
-    // slicing-by-8 tables: tab[k][v] = register after byte v followed by k zero bytes (from a zero register)
-    __shared__ uint32_t tab[8][256];
-    __shared__ uint32_t part[CRC_NT];
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t tab[8][256];       // slicing-by-8: register after byte v followed by k zero bytes
+    __shared__ uint32_t tabx[4][256];      // (v << 8k) * x^(8*65536) mod P
+    __shared__ __attribute__((aligned(16))) uint8_t buf[CRC_NT * CRC_PITCH];
+    __shared__ uint32_t red[CRC_NT / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid < 256) {
         uint32_t c = tid << 24;
         for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : (c << 1);
@@ -510,38 +521,75 @@ __global__ __launch_bounds__(CRC_NT) void bzx_rl_crc_kernel(const uint8_t *__res
         }
         __syncthreads();
     }
+    {
+        const uint32_t xt = gf_xpow8(CRC_TILE);
+        tabx[tid >> 8][tid & 255u] = gf_mulmod((tid & 255u) << (8 * (tid >> 8)), xt);
+    }
+    const uint32_t my_weight = gf_xpow8((uint64_t)CRC_SUB * (CRC_NT - 1 - tid));     // x^(8*64*(1023-t))
+    __syncthreads();
     const uint32_t nblk = ws.nblk[0];
     for (uint32_t b = own_first + blockIdx.x * own_step; b < nblk; b += gridDim.x * own_step) {
         const uint64_t lo = ws.blk_raw[b], hi = ws.blk_raw[b + 1];
         const uint64_t total = hi - lo;
-        const uint64_t per = (total + CRC_NT - 1) / CRC_NT;
-        const uint64_t a = lo + (uint64_t)tid * per < hi ? lo + (uint64_t)tid * per : hi;
-        const uint64_t e = a + per < hi ? a + per : hi;
-        uint32_t r = 0;
-        uint64_t p = a;
-        for (; p + 8 <= e; p += 8) {
-            uint64_t w;
-            __builtin_memcpy(&w, raw + p, 8);                 // unaligned 8-byte load
-            const uint32_t w0 = __builtin_bswap32((uint32_t)w) ^ r, w1 = __builtin_bswap32((uint32_t)(w >> 32));
-            r = tab[7][w0 >> 24] ^ tab[6][(w0 >> 16) & 255u] ^ tab[5][(w0 >> 8) & 255u] ^ tab[4][w0 & 255u] ^
-                tab[3][w1 >> 24] ^ tab[2][(w1 >> 16) & 255u] ^ tab[1][(w1 >> 8) & 255u] ^ tab[0][w1 & 255u];
-        }
-        for (; p < e; p++) r = (r << 8) ^ tab[0][(r >> 24) ^ raw[p]];
-        part[tid] = r;
-        __syncthreads();
-        // fold: state = state * x^(8 len_i) + r_i over the 1024 chunks (GF(2) polynomial arithmetic mod P)
-        if (tid == 0) {
-            uint32_t s = 0xffffffffu;
-            const uint32_t xp = gf_xpow8(per);
-            for (uint32_t i = 0; i < CRC_NT; i++) {
-                const uint64_t ai = lo + (uint64_t)i * per;
-                if (ai >= hi) break;
-                const uint64_t li = ai + per < hi ? per : hi - ai;
-                s = gf_mulmod(s, li == per ? xp : gf_xpow8(li)) ^ part[i];
+        const uint64_t ntile = (total + CRC_TILE - 1) / CRC_TILE;
+        uint32_t R = 0;
+        // piece e of lane t in a tile = bytes [(e*1024 + t)*16, +16) of the tile; tile k starts at hi - (ntile-k)*64K
+        uint4 nx[4];
+        auto load_piece = [&](int64_t p) -> uint4 {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (p >= (int64_t)lo) {
+                __builtin_memcpy(&v, raw + p, 16);
+            } else if (p + 16 > (int64_t)lo) {
+                uint8_t tmp[16];
+                for (int j = 0; j < 16; j++) tmp[j] = (p + j >= (int64_t)lo) ? raw[p + j] : (uint8_t)0;
+                __builtin_memcpy(&v, tmp, 16);
             }
-            blk[b].crc = ~s;
+            return v;
+        };
+        int64_t t0 = (int64_t)hi - (int64_t)(ntile * CRC_TILE);
+#pragma unroll
+        for (int e = 0; e < 4; e++) nx[e] = ntile ? load_piece(t0 + (int64_t)(e * CRC_NT + tid) * 16) : make_uint4(0, 0, 0, 0);
+        for (uint64_t k = 0; k < ntile; k++) {
+            uint4 cur[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) cur[e] = nx[e];
+            t0 += CRC_TILE;
+            if (k + 1 < ntile) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) nx[e] = load_piece(t0 + (int64_t)(e * CRC_NT + tid) * 16);
+            }
+            __syncthreads();                       // previous tile fully consumed
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t o = (uint32_t)(e * CRC_NT + tid) * 16;              // byte offset inside the tile
+                uint64_t *dst = reinterpret_cast<uint64_t *>(buf + (o / CRC_SUB) * CRC_PITCH + (o % CRC_SUB));
+                dst[0] = (uint64_t)cur[e].x | ((uint64_t)cur[e].y << 32);
+                dst[1] = (uint64_t)cur[e].z | ((uint64_t)cur[e].w << 32);
+            }
+            __syncthreads();
+            const uint64_t *src = reinterpret_cast<const uint64_t *>(buf + tid * CRC_PITCH);
+            uint32_t r = 0;
+#pragma unroll
+            for (int q = 0; q < CRC_SUB / 8; q++) {
+                const uint64_t w = src[q];
+                const uint32_t w0 = __builtin_bswap32((uint32_t)w) ^ r, w1 = __builtin_bswap32((uint32_t)(w >> 32));
+                r = tab[7][w0 >> 24] ^ tab[6][(w0 >> 16) & 255u] ^ tab[5][(w0 >> 8) & 255u] ^ tab[4][w0 & 255u] ^
+                    tab[3][w1 >> 24] ^ tab[2][(w1 >> 16) & 255u] ^ tab[1][(w1 >> 8) & 255u] ^ tab[0][w1 & 255u];
+            }
+            R = tabx[3][R >> 24] ^ tabx[2][(R >> 16) & 255u] ^ tabx[1][(R >> 8) & 255u] ^ tabx[0][R & 255u] ^ r;
         }
+        // D = xor over lanes of R_t * weight_t
+        uint32_t d = gf_mulmod(R, my_weight);
+#pragma unroll
+        for (int s2 = 32; s2 > 0; s2 >>= 1) d ^= __shfl_xor(d, s2);
         __syncthreads();
+        if (lane == 0) red[wave] = d;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t D = 0;
+            for (uint32_t i = 0; i < CRC_NT / 64; i++) D ^= red[i];
+            blk[b].crc = ~(gf_mulmod(0xffffffffu, gf_xpow8(total)) ^ D);
+        }
     }
 }
 
@@ -591,7 +639,7 @@ void bzx_split_launch_scatter(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, co
     const uint32_t grid = (uint32_t)(ntiles < (uint64_t)bzx_ctx_ncu(ctx) * 8 ? ntiles : (uint64_t)bzx_ctx_ncu(ctx) * 8);
     hipLaunchKernelGGL(bzx_rl_scatter_kernel, dim3(grid), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, ws, d_slabs, d_blk, own_first, own_step);
     const uint32_t mine = nblk > own_first ? (nblk - own_first + own_step - 1) / own_step : 0;
-    const uint32_t cgrid = mine < (uint32_t)bzx_ctx_ncu(ctx) * 2 ? (mine ? mine : 1) : (uint32_t)bzx_ctx_ncu(ctx) * 2;
+    const uint32_t cgrid = mine < (uint32_t)bzx_ctx_ncu(ctx) ? (mine ? mine : 1) : (uint32_t)bzx_ctx_ncu(ctx);
     hipLaunchKernelGGL(bzx_rl_crc_kernel, dim3(cgrid), dim3(CRC_NT), 0, st, d_raw, ws, d_blk, own_first, own_step);
 }
 
