@@ -115,10 +115,16 @@ __global__ __launch_bounds__(1024) void bzx_rl_scan_kernel(uint64_t *v, uint64_t
     const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (uint64_t i0 = 0; i0 < n; i0 += 1024) {
-        const uint64_t i = i0 + tid;
-        const uint64_t x0 = i < n ? v[i] : 0ull;
-        uint64_t x = x0;
+    constexpr int E = 8;                   // consecutive elements per lane
+    for (uint64_t i0 = 0; i0 < n; i0 += 1024 * E) {
+        const uint64_t ib = i0 + (uint64_t)tid * E;
+        uint64_t a[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) a[j] = ib + j < n ? v[ib + j] : 0ull;
+        uint64_t mine = 0;                 // combination of my E elements
+#pragma unroll
+        for (int j = 0; j < E; j++) mine = is_max ? (a[j] > mine ? a[j] : mine) : mine + a[j];
+        uint64_t x = mine;
         for (uint32_t d = 1; d < 64; d <<= 1) {
             const uint64_t y = __shfl_up(x, d);
             if (lane >= d) x = is_max ? (y > x ? y : x) : x + y;
@@ -146,7 +152,11 @@ __global__ __launch_bounds__(1024) void bzx_rl_scan_kernel(uint64_t *v, uint64_t
         } else {
             r = carry + pre + ex;
         }
-        if (i < n) v[i] = r;
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            if (ib + j < n) v[ib + j] = r;
+            r = is_max ? (a[j] > r ? a[j] : r) : r + a[j];
+        }
         __syncthreads();
         if (tid == 0) carry_s = is_max ? (tot > carry ? tot : carry) : carry + tot;
         __syncthreads();
