@@ -68,6 +68,7 @@ struct BitW {
 
 __shared__ uint8_t e_len[6][BZX_MAX_ALPHA + 2];
 __shared__ uint32_t e_code[6][BZX_MAX_ALPHA + 2];
+__shared__ uint32_t e_cl[6][BZX_MAX_ALPHA + 2];     // code | length << 24: one lookup per payload symbol
 __shared__ uint32_t e_tabbits[8];
 __shared__ uint32_t e_scratch[2 * EMIT_NW];
 __shared__ uint32_t e_bcast[4];
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
             if (v < BZX_MAX_ALPHA + 2) {
                 e_len[t][v] = B.len[(size_t)b * 6 * 260 + i];
                 e_code[t][v] = B.code[(size_t)b * 6 * 260 + i];
+                e_cl[t][v] = B.code[(size_t)b * 6 * 260 + i] | ((uint32_t)B.len[(size_t)b * 6 * 260 + i] << 24);
             }
         }
         __syncthreads();
@@ -217,19 +219,19 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
                     const uint32_t gs = g * BZX_G_SIZE;
                     const uint32_t cnt = (n_mtf - gs < BZX_G_SIZE) ? n_mtf - gs : BZX_G_SIZE;
                     const uint32_t *__restrict__ vp = reinterpret_cast<const uint32_t *>(V + gs);
-                    const uint32_t bt = SEL[g];
+                    const uint32_t *__restrict__ cl = e_cl[SEL[g]];
+                    // all loads of the group first (25 words in flight), then all table lookups, then the packing
+                    uint32_t vw[BZX_G_SIZE / 2];
+#pragma unroll
+                    for (uint32_t k = 0; k < BZX_G_SIZE / 2; k++) vw[k] = 2 * k < cnt ? vp[k] : 0u;
                     BitW w;
                     w.init(out, o_pay + carry + ex);
+#pragma unroll
                     for (uint32_t k = 0; k < BZX_G_SIZE / 2; k++) {
-                        const uint32_t sy = vp[k];
-                        if (2 * k < cnt) {
-                            const uint32_t s = sy & 0xffffu;
-                            w.put(e_len[bt][s], e_code[bt][s]);
-                        }
-                        if (2 * k + 1 < cnt) {
-                            const uint32_t s = sy >> 16;
-                            w.put(e_len[bt][s], e_code[bt][s]);
-                        }
+                        const uint32_t c0 = 2 * k < cnt ? cl[vw[k] & 0xffffu] : 0u;
+                        const uint32_t c1 = 2 * k + 1 < cnt ? cl[vw[k] >> 16] : 0u;
+                        w.put(c0 >> 24, c0 & 0xffffffu);
+                        w.put(c1 >> 24, c1 & 0xffffffu);
                     }
                     w.finish();
                 }
