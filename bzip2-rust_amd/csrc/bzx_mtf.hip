@@ -61,8 +61,10 @@ __device__ __forceinline__ void mtf_ranks_regs(const uint8_t *__restrict__ L, ui
     uint64_t w[NWORD];
 #pragma unroll
     for (int i = 0; i < NWORD; i++) w[i] = lst64[i];
+    uint4 nxt = c_lo < c_hi ? *reinterpret_cast<const uint4 *>(L + c_lo) : make_uint4(0, 0, 0, 0);
     for (uint32_t i0 = c_lo; i0 < c_hi; i0 += 16) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(L + i0);
+        const uint4 v = nxt;
+        if (i0 + 16 < c_hi) nxt = *reinterpret_cast<const uint4 *>(L + i0 + 16);     // in flight during the 16 steps below
         const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
         uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -182,8 +184,10 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
             uint32_t cnt = 0;
             uint8_t *rec = m_rec + tid * stride;
             // 16 bytes per load, walking backwards (chunk starts are 16-byte aligned, slabs 256-byte aligned)
+            uint4 nxt = *reinterpret_cast<const uint4 *>(L + ((c_hi - 1) & ~15u));
             for (uint32_t i0 = (c_hi - 1) & ~15u; cnt < n_in_use;) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(L + i0);
+                const uint4 v = nxt;
+                if (i0 != c_lo) nxt = *reinterpret_cast<const uint4 *>(L + i0 - 16);
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int q = 3; q >= 0; q--) {
@@ -270,8 +274,10 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
             uint64_t *lst64 = reinterpret_cast<uint64_t *>(m_list + tid * stride);
             uint64_t w = lst64[0];
             const uint64_t ones = 0x0101010101010101ull, highs = 0x8080808080808080ull;
+            uint4 nxt = *reinterpret_cast<const uint4 *>(L + c_lo);
             for (uint32_t i0 = c_lo; i0 < c_hi; i0 += 16) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(L + i0);
+                const uint4 v = nxt;
+                if (i0 + 16 < c_hi) nxt = *reinterpret_cast<const uint4 *>(L + i0 + 16);
                 const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
                 uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
