@@ -40,6 +40,10 @@ struct bzx_ctx {
     int n_cu = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // second stream: MTF of finished blocks runs beside the last (partial) round of the sort
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint32_t bwt_launches = 1;       // BWT kernel launches of the last run (telemetry)
     std::string err;
 
     uint32_t cap_blocks = 0;   // per-block slab capacity
@@ -194,6 +198,12 @@ extern "C" int bzx_ctx_create(int device, uint32_t max_blocks, bzx_ctx **out)
     }
     ctx->own_stream = true;
     for (int i = 0; i < 8; i++) (void)hipEventCreate(&ctx->ev[i]);
+    if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        bzx_ctx_destroy(ctx);
+        return BZX_E_HIP;
+    }
     bool ok = hipMalloc((void **)&ctx->d_counters, 64 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&ctx->d_scalars, 8 * sizeof(uint64_t)) == hipSuccess &&
               hipHostMalloc((void **)&ctx->h_scalars, 8 * sizeof(uint64_t), 0) == hipSuccess;
@@ -218,6 +228,9 @@ extern "C" void bzx_ctx_destroy(bzx_ctx *ctx)
     if (ctx->h_blk) (void)hipHostFree(ctx->h_blk);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -260,16 +273,58 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
     if (B.blk_step == 0) B.blk_step = 1;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 64 * sizeof(uint32_t), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    B.ctr_bwt = 0;
+    B.ctr_mtf = 1;
+    ctx->bwt_launches = 1;
+    bool mtf_done = false;
     if ((stages & STG_BWT) && nblk) {
         uint32_t per_cu = bzx_bwt_max_blocks_per_cu();
         uint32_t grid = grid_for(ctx, nblk, per_cu);
         int rc = ensure_slots(ctx, (uint32_t)ctx->n_cu * per_cu);
         if (rc) return rc;
-        bzx_launch_bwt(B, grid, ctx->stream);
-        bzx_launch_periodic(B, grid < 16 ? grid : 16, ctx->stream);   // no-op unless blocks were flagged periodic
+        // The sort runs one workgroup per compute unit, so its last round leaves (n_cu - nblk % n_cu) units idle
+        // for a whole block time.  With enough blocks, sort the full rounds first, then run the partial round
+        // beside the MTF stage of blocks that are already sorted (second stream, exactly the idle units).
+        const uint32_t ncu = (uint32_t)ctx->n_cu;
+        const uint32_t rem = nblk % ncu, idle = ncu - rem;
+        if ((stages & STG_MTF) && per_cu == 1 && nblk > ncu && rem != 0 && idle * 8 >= ncu) {
+            const uint32_t full = nblk - rem;
+            const uint32_t n_a1 = full < idle * 5 ? full : idle * 5;      // a block sorts in roughly 5 MTF times
+            BzxBatch Ba = B;
+            Ba.nblk = full;
+            bzx_launch_bwt(Ba, ncu, ctx->stream);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            BzxBatch Bb = B;
+            Bb.blk_first = B.blk_first + full * B.blk_step;
+            Bb.nblk = rem;
+            Bb.ctr_bwt = 6;
+            bzx_launch_bwt(Bb, rem, ctx->stream);
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+            BzxBatch Bm = B;
+            Bm.nblk = n_a1;
+            Bm.ctr_mtf = 7;
+            bzx_launch_mtf(Bm, idle < n_a1 ? idle : n_a1, ctx->aux);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+            bzx_launch_periodic(B, 16, ctx->stream);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+            if (nblk > n_a1) {
+                BzxBatch Br = B;
+                Br.blk_first = B.blk_first + n_a1 * B.blk_step;
+                Br.nblk = nblk - n_a1;
+                bzx_launch_mtf(Br, grid_for(ctx, Br.nblk, 1), ctx->stream);
+            }
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            ctx->bwt_launches = 2;
+            mtf_done = true;
+        } else {
+            bzx_launch_bwt(B, grid, ctx->stream);
+            bzx_launch_periodic(B, grid < 16 ? grid : 16, ctx->stream);   // no-op unless blocks were flagged periodic
+        }
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    if ((stages & STG_MTF) && nblk) bzx_launch_mtf(B, grid_for(ctx, nblk, 1), ctx->stream);
+    if (!mtf_done) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+        if ((stages & STG_MTF) && nblk) bzx_launch_mtf(B, grid_for(ctx, nblk, 1), ctx->stream);
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     if ((stages & STG_HUF) && nblk) bzx_launch_huffman(B, grid_for(ctx, nblk, 3), ctx->stream);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
@@ -326,6 +381,7 @@ static void collect_stage_times(bzx_ctx *ctx)
     float ms[4] = {0, 0, 0, 0};
     for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]);
     ctx->stats.ms_bwt = ms[0];
+    ctx->stats.bwt_launches = ctx->bwt_launches;
     ctx->stats.ms_mtf = ms[1];
     ctx->stats.ms_huffman = ms[2];
     ctx->stats.ms_emit = ms[3];

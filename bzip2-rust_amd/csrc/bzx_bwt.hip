@@ -925,7 +925,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
     const BzxSortWs ws = B.sort_ws[blockIdx.x];
 
     for (;;) {
-        if (tid == 0) s_bcast[0] = atomicAdd(&B.counters[0], 1u);
+        if (tid == 0) s_bcast[0] = atomicAdd(&B.counters[B.ctr_bwt], 1u);
         __syncthreads();
         const uint32_t j_ = s_bcast[0];
         __syncthreads();

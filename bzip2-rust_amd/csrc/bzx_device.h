@@ -56,6 +56,8 @@ struct BzxBatch {
     uint32_t nblk;          // blocks this launch works on: logical j in [0,nblk) -> block blk_first + j*blk_step
     uint32_t blk_first;     // round-robin sharding over GPUs: first = rank, step = world size
     uint32_t blk_step;
+    uint32_t ctr_bwt;       // index of the block-fetch counter this BWT launch uses (0, or 6 for a concurrent second launch)
+    uint32_t ctr_mtf;       // same for the MTF kernel (1 or 7)
     uint32_t packed;        // emit at blk.pack_word (packed per-rank buffer) instead of blk.out_bit (final stream)
     uint32_t *counters;     // [64] atomic work counters, one per stage kernel (zeroed per batch); [5] = #periodic
     uint32_t *plist;        // [nblk] indices of the blocks flagged periodic by the BWT kernel

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
     unsigned long long t_last = 0;
 
     for (;;) {
-        if (tid == 0) m_bcast[0] = atomicAdd(&B.counters[1], 1u);
+        if (tid == 0) m_bcast[0] = atomicAdd(&B.counters[B.ctr_mtf], 1u);
         __syncthreads();
         const uint32_t j_ = m_bcast[0];
         __syncthreads();

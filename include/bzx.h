@@ -136,6 +136,9 @@ typedef struct {
     uint64_t mtf_symbols;       /* nMTF summed */
     uint64_t out_bits;          /* compressed bits incl. stream header/footer when present */
     float ms_split, ms_bwt, ms_mtf, ms_huffman, ms_emit, ms_total;   /* HIP-event times of the stage kernels */
+    uint32_t bwt_launches;      /* launches of the BWT kernel in the last run (2 when its partial last round
+                                   ran beside the MTF stage on a second stream); ms_bwt covers all of them */
+    uint32_t reserved_;
 } bzx_stats;
 int bzx_get_stats(const bzx_ctx *ctx, bzx_stats *out);
 

@@ -18,7 +18,8 @@ class BzxStats(C.Structure):
     _fields_ = [("nblk", C.c_uint32), ("n_periodic", C.c_uint32), ("raw_bytes", C.c_uint64),
                 ("rle1_bytes", C.c_uint64), ("mtf_symbols", C.c_uint64), ("out_bits", C.c_uint64),
                 ("ms_split", C.c_float), ("ms_bwt", C.c_float), ("ms_mtf", C.c_float),
-                ("ms_huffman", C.c_float), ("ms_emit", C.c_float), ("ms_total", C.c_float)]
+                ("ms_huffman", C.c_float), ("ms_emit", C.c_float), ("ms_total", C.c_float),
+                ("bwt_launches", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class BzxError(RuntimeError):

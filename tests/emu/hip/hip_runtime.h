@@ -145,6 +145,11 @@ inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+#define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = 0; return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = 0; return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
 inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
