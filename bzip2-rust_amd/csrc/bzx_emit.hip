@@ -279,9 +279,24 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_layout_kernel(BzxBatch B, uint64_
 }
 
 // "BZh<level>" at bit 0, footer magic + combined CRC behind the last block; out_bytes[0] = stream length.
-__global__ void bzx_stream_frame_kernel(BzxBatch B, int level, const uint64_t *total, uint64_t *out_bytes)
+__global__ __launch_bounds__(256) void bzx_stream_frame_kernel(BzxBatch B, int level, const uint64_t *total,
+                                                               uint64_t *out_bytes)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // combined CRC (crc.rs:25-27): c = rotl(c, 1) ^ crc_b over the blocks in order.  Rotation is linear over
+    // XOR, so c = XOR_b rotl(crc_b, (nblk - 1 - b) mod 32): one pass over the descriptors by the whole workgroup.
+    __shared__ uint32_t part[4];
+    if (blockIdx.x != 0) return;
+    uint32_t x = 0;
+    for (uint32_t b = threadIdx.x; b < B.nblk; b += blockDim.x) {
+        const uint32_t c = B.blk[b].crc, r = (B.nblk - 1u - b) & 31u;
+        x ^= r ? ((c << r) | (c >> (32u - r))) : c;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x ^= __shfl_xor(x, d);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const uint32_t combined = part[0] ^ part[1] ^ part[2] ^ part[3];
     BitW w;
     w.init(B.out, 0);
     w.put(8, 'B');
@@ -289,8 +304,6 @@ __global__ void bzx_stream_frame_kernel(BzxBatch B, int level, const uint64_t *t
     w.put(8, 'h');
     w.put(8, (uint32_t)('0' + level));
     w.finish();
-    uint32_t combined = 0;
-    for (uint32_t b = 0; b < B.nblk; b++) combined = ((combined << 1) | (combined >> 31)) ^ B.blk[b].crc;
     const uint64_t end = total[0];
     w.init(B.out, end);
     w.put(24, 0x177245u);
@@ -406,5 +419,5 @@ void bzx_launch_layout(const BzxBatch &B, uint64_t first_bit, uint64_t stride_bi
 void bzx_launch_stream_frame(const BzxBatch &B, int level, const uint64_t *d_total_bits, uint64_t *d_out_bytes,
                              hipStream_t stream)
 {
-    hipLaunchKernelGGL(bzx_stream_frame_kernel, dim3(1), dim3(64), 0, stream, B, level, d_total_bits, d_out_bytes);
+    hipLaunchKernelGGL(bzx_stream_frame_kernel, dim3(1), dim3(256), 0, stream, B, level, d_total_bits, d_out_bytes);
 }

@@ -226,6 +226,35 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_count_kernel(const uint8_t *__re
     __shared__ uint64_t s64[RL_NT / 64];
     __shared__ uint32_t s32[RL_NT / 64];
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // Cheap test first: a tile in which no four consecutive equal bytes end (looking 3 bytes back into the
+        // previous tile) has no run position k >= 3, so RLE1 copies it: emitted bytes = tile bytes.  The test
+        // may report a run that is not there (borrow in the zero-byte trick), never miss one.
+        if (tile > 0 && (tile + 1) * RL_TILE <= len) {
+            const uint64_t p0 = tile * RL_TILE + (uint64_t)threadIdx.x * RL_BYTES;
+            uint32_t w[9];
+            __builtin_memcpy(&w[0], raw + p0 - 4, 4);
+            const uint4 a = *reinterpret_cast<const uint4 *>(raw + p0);
+            const uint4 b = *reinterpret_cast<const uint4 *>(raw + p0 + 16);
+            w[1] = a.x; w[2] = a.y; w[3] = a.z; w[4] = a.w;
+            w[5] = b.x; w[6] = b.y; w[7] = b.z; w[8] = b.w;
+            uint64_t m = 0;                      // bit i: byte i of the 36 equals byte i+1
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const uint32_t nxt = i < 8 ? w[i + 1] : ~w[8];
+                const uint32_t z = w[i] ^ ((w[i] >> 8) | (nxt << 24));
+                const uint32_t f = ((z - 0x01010101u) & ~z & 0x80808080u) >> 7;      // 0x01 in every zero byte (or above one)
+                m |= (uint64_t)((f * 0x01020408u) >> 24 & 0xFu) << (4 * i);
+            }
+            m >>= 1;                             // pairs starting at byte p0-3 and later
+            const bool run4 = (m & (m >> 1) & (m >> 2)) != 0;
+            if (!__syncthreads_or(run4)) {
+                if (threadIdx.x == 0) {
+                    ws.tile_off[tile] = RL_TILE;
+                    ws.tile_np[tile] = 0;
+                }
+                continue;
+            }
+        }
         TileInfo ti;
         tile_analyse(raw, len, tile, ws, s64, s32, ti);
         const bool np = __syncthreads_or(ti.any_long);
@@ -250,6 +279,8 @@ __device__ uint64_t piece_end(const uint8_t *__restrict__ raw, uint64_t len, uin
     return q;
 }
 
+#define BND_J 64                       // blocks per batch of the fast path
+#define BND_W (4 * BND_J + 16)         // window bytes per predicted boundary (drift <= 4 per block), multiple of 16
 // ---- C: block boundaries (single workgroup, serial over blocks)
 __global__ __launch_bounds__(RL_NT) void bzx_rl_boundaries_kernel(const uint8_t *__restrict__ raw, uint64_t len,
                                                                   uint64_t ntiles, uint32_t nmax, BzxSplitWs ws)
@@ -259,11 +290,64 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_boundaries_kernel(const uint8_t 
     __shared__ uint64_t s_x;      // candidate position
     __shared__ uint32_t s_k;      // k at the candidate
     __shared__ uint64_t s_next, s_fnext;
+    // windows of raw bytes around the next BND_J predicted boundaries (see the batched fast path below)
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[BND_J][BND_W];
     const uint32_t tid = threadIdx.x;
     uint64_t start = 0, f_start = 0;
     uint32_t nb = 0;
     const uint64_t f_len = ws.tile_off[ntiles];
     while (start < len && nb < ws.max_blocks) {
+        // ---- batched fast path: when no tile that the next J blocks can touch has a run position k >= 3, RLE1 is
+        // the identity on all of them and block j ends within 4 bytes of start + (j+1) nmax + (0..4j).  The raw
+        // bytes around all J predicted boundaries are fetched in one round trip into LDS, then the serial chain
+        // (every lane runs it redundantly, lane 0 stores) costs LDS latency per block instead of HBM latency.
+        {
+            uint32_t J = BND_J;
+            const uint64_t room = len > start + BND_W + 16 ? (len - start - BND_W - 16) / nmax : 0;   // blocks that end well before len
+            if (room < J + 1) J = room > 1 ? (uint32_t)room - 1 : 0;
+            if (nb + J > ws.max_blocks) J = ws.max_blocks - nb;
+            if (J >= 2) {
+                const uint64_t last = start + (uint64_t)(J + 1) * nmax + 4 * J + 8;
+                uint64_t t1 = last / RL_TILE + 2;
+                if (t1 > ntiles) t1 = ntiles;
+                if (ws.tile_np[t1] != ws.tile_np[start / RL_TILE]) J = 0;
+            }
+            if (J >= 2) {
+                for (uint32_t i = tid; i < J * (BND_W / 16); i += RL_NT) {
+                    const uint32_t j = i / (BND_W / 16), c = i % (BND_W / 16);
+                    uint4 v;
+                    __builtin_memcpy(&v, raw + start + (uint64_t)(j + 1) * nmax - 4 + 16 * c, 16);
+                    *reinterpret_cast<uint4 *>(&s_win[j][16 * c]) = v;
+                }
+                __syncthreads();
+                const uint64_t start0 = start;
+                for (uint32_t j = 0; j < J; j++) {
+                    if (tid == 0) {
+                        ws.blk_raw[nb] = start;
+                        ws.blk_f[nb] = f_start;
+                        ws.blk_plain[nb] = 1;
+                    }
+                    nb++;
+                    const uint64_t x = start + nmax;
+                    const uint8_t *w = &s_win[j][(uint32_t)(start - (start0 + (uint64_t)j * nmax))];   // bytes x-4 .. x+3
+                    uint32_t k = 0;
+                    while (k < 3 && w[3 - k] == w[4]) k++;
+                    uint64_t q = x;
+                    if (k) {
+                        q = x + 1;
+                        uint32_t kk = k + 1;
+                        while (kk < 4 && q < x + 4 && w[4 + (q - x)] == w[4]) {
+                            q++;
+                            kk++;
+                        }
+                    }
+                    f_start += q - start;
+                    start = q;
+                }
+                __syncthreads();
+                continue;
+            }
+        }
         if (tid == 0) {
             ws.blk_raw[nb] = start;
             ws.blk_f[nb] = f_start;

@@ -45,7 +45,9 @@ def test_emu_split_and_stream(emu, oracle):
     runs = bytearray()
     while len(runs) < 150000:
         runs += bytes([rnd.choice(b"ab\0")]) * rnd.randint(1, 400)
-    for data, level in ((oracle.synthtext(130000), 1), (bytes(runs), 1), (b"", 9), (b"xyz", 9)):
+    big = oracle.synthtext(520000)          # several plain blocks: the batched fast path of the boundary chain
+    mixed = big[:260000] + b"\0" * 5000 + big[260000:] + b"ab" * 3      # ... and a long run that interrupts it
+    for data, level in ((oracle.synthtext(130000), 1), (bytes(runs), 1), (b"", 9), (b"xyz", 9), (big, 1), (mixed, 1)):
         assert emu.split_rle1(data, level) == oracle.split_rle1(data, level)
     data = oracle.synthtext(60000) + b"\0" * 2000 + oracle.synthtext(45000)
     assert emu.compress_buffer(data, 1) == bz2.compress(data, 1)
