@@ -99,28 +99,74 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_runstart_kernel(const uint8_t *_
     __shared__ uint64_t scratch[RL_NT / 64];
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         TileLane t;
-        tile_load(raw, len, tile, t);
+        bool run4 = true;                   // "this tile may hold a run position k >= 3": decided exactly by kernel B
+        if (tile > 0 && (tile + 1) * RL_TILE <= len) {
+            // Full inner tile: one load serves the run starts and a cheap test for B: a tile in which no four
+            // consecutive equal bytes end (looking 3 bytes back into the previous tile) has no run position
+            // k >= 3, so RLE1 copies it.
+            t.p0 = tile * RL_TILE + (uint64_t)threadIdx.x * RL_BYTES;
+            t.nvalid = RL_BYTES;
+            uint32_t w0;
+            __builtin_memcpy(&w0, raw + t.p0 - 4, 4);
+            const uint4 a = *reinterpret_cast<const uint4 *>(raw + t.p0);
+            const uint4 b = *reinterpret_cast<const uint4 *>(raw + t.p0 + 16);
+            t.w[0] = a.x; t.w[1] = a.y; t.w[2] = a.z; t.w[3] = a.w;
+            t.w[4] = b.x; t.w[5] = b.y; t.w[6] = b.z; t.w[7] = b.w;
+            t.prev = w0 >> 24;
+            uint64_t m = 0;                      // bit i: byte i of the 36 (from p0 - 4) equals byte i+1
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const uint32_t cur = i ? t.w[i - 1] : w0;
+                const uint32_t nxt = i < 8 ? t.w[i] : ~t.w[7];
+                const uint32_t z = cur ^ ((cur >> 8) | (nxt << 24));
+                const uint32_t f = ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z | 0x7F7F7F7Fu) >> 7;   // 0x01 in exactly the zero bytes
+                m |= (uint64_t)((f * 0x01020408u) >> 24 & 0xFu) << (4 * i);
+            }
+            m >>= 1;                             // pairs starting at byte p0-3 and later
+            run4 = (m & (m >> 1) & (m >> 2)) != 0;
+        } else {
+            tile_load(raw, len, tile, t);
+        }
         uint64_t tot;
         (void)block_excl_max64(lane_last_rs(t), scratch, tot);
-        if (threadIdx.x == 0) ws.tile_rs[tile] = tot;
+        const bool any4 = __syncthreads_or(run4);
+        if (threadIdx.x == 0) {
+            ws.tile_rs[tile] = tot;
+            ws.tile_np[tile] = any4 ? 1 : 0;     // provisional: 0 = plain for sure, B skips the tile
+            ws.tile_off[tile] = RL_TILE;
+        }
     }
 }
 
 // ---- S1 / S2: single-workgroup exclusive scans over the tile summaries
-__global__ __launch_bounds__(1024) void bzx_rl_scan_kernel(uint64_t *v, uint64_t n, int is_max)
+__global__ __launch_bounds__(1024) void bzx_rl_scan_kernel(uint64_t *v_all, uint64_t n_all, int is_max, uint64_t seg,
+                                                           uint64_t *tot_out)
 {
-    // v[0..n) -> exclusive scan in place; v[n] = total
-    __shared__ uint64_t wsum[16];
-    __shared__ uint64_t carry_s;
+    // Workgroup g: v_all[g seg .. min(n_all, (g+1) seg)) -> exclusive scan in place; tot_out[g] = its total.
+    // (One workgroup with seg >= n_all and tot_out = v_all + n_all scans a whole array.)  8 consecutive elements
+    // per lane, the next iteration's elements already in flight; one barrier per iteration (wave totals
+    // double-buffered, every lane keeps the running carry itself).
+    const uint64_t lo_ = (uint64_t)blockIdx.x * seg;
+    if (lo_ >= n_all && blockIdx.x) return;
+    uint64_t *v = v_all + lo_;
+    const uint64_t n = lo_ >= n_all ? 0 : (n_all - lo_ < seg ? n_all - lo_ : seg);
+    __shared__ uint64_t wsum[2][16];
     const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    constexpr int E = 8;                   // consecutive elements per lane
-    for (uint64_t i0 = 0; i0 < n; i0 += 1024 * E) {
+    constexpr int E = 8;
+    uint64_t carry = 0;
+    uint64_t nx[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) nx[j] = (uint64_t)tid * E + j < n ? v[(uint64_t)tid * E + j] : 0ull;
+    int buf = 0;
+    for (uint64_t i0 = 0; i0 < n; i0 += 1024 * E, buf ^= 1) {
         const uint64_t ib = i0 + (uint64_t)tid * E;
         uint64_t a[E];
 #pragma unroll
-        for (int j = 0; j < E; j++) a[j] = ib + j < n ? v[ib + j] : 0ull;
+        for (int j = 0; j < E; j++) {
+            a[j] = nx[j];
+            const uint64_t in = ib + 1024 * E + j;
+            nx[j] = in < n ? v[in] : 0ull;
+        }
         uint64_t mine = 0;                 // combination of my E elements
 #pragma unroll
         for (int j = 0; j < E; j++) mine = is_max ? (a[j] > mine ? a[j] : mine) : mine + a[j];
@@ -131,12 +177,11 @@ __global__ __launch_bounds__(1024) void bzx_rl_scan_kernel(uint64_t *v, uint64_t
         }
         uint64_t ex = __shfl_up(x, 1);
         if (lane == 0) ex = 0;
-        if (lane == 63) wsum[wave] = x;
-        const uint64_t carry = carry_s;
+        if (lane == 63) wsum[buf][wave] = x;
         __syncthreads();
         uint64_t pre = 0, tot = 0;
         for (uint32_t w = 0; w < 16; w++) {
-            const uint64_t s = wsum[w];
+            const uint64_t s = wsum[buf][w];
             if (is_max) {
                 if (w < wave && s > pre) pre = s;
                 if (s > tot) tot = s;
@@ -157,11 +202,39 @@ __global__ __launch_bounds__(1024) void bzx_rl_scan_kernel(uint64_t *v, uint64_t
             if (ib + j < n) v[ib + j] = r;
             r = is_max ? (a[j] > r ? a[j] : r) : r + a[j];
         }
-        __syncthreads();
-        if (tid == 0) carry_s = is_max ? (tot > carry ? tot : carry) : carry + tot;
-        __syncthreads();
+        carry = is_max ? (tot > carry ? tot : carry) : carry + tot;
     }
-    if (tid == 0) v[n] = carry_s;
+    if (tid == 0) tot_out[blockIdx.x] = carry;
+}
+
+// second level of a segmented scan: element i of segment g gets the scanned segment total off[g] combined in
+__global__ __launch_bounds__(1024) void bzx_rl_scan_add_kernel(uint64_t *v, uint64_t n, int is_max, uint64_t seg,
+                                                               const uint64_t *off, uint64_t nseg)
+{
+    const uint64_t o = off[blockIdx.x];
+    const uint64_t lo = (uint64_t)blockIdx.x * seg, hi = lo + seg < n ? lo + seg : n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        const uint64_t x = v[i];
+        v[i] = is_max ? (x > o ? x : o) : x + o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) v[n] = off[nseg];
+}
+
+#ifndef SCAN_SEG
+#define SCAN_SEG 8192        // the emulator build uses a tiny segment so that small inputs take the two-level path
+#endif
+// v[0..n) -> exclusive scan in place, v[n] = total.  segtot: scratch of n / SCAN_SEG + 2 words.
+static void launch_scan(hipStream_t st, uint64_t *v, uint64_t n, int is_max, uint64_t *segtot)
+{
+    if (n <= 2 * SCAN_SEG) {
+        hipLaunchKernelGGL(bzx_rl_scan_kernel, dim3(1), dim3(1024), 0, st, v, n, is_max, n ? n : 1, v + n);
+        return;
+    }
+    const uint64_t nseg = (n + SCAN_SEG - 1) / SCAN_SEG;
+    hipLaunchKernelGGL(bzx_rl_scan_kernel, dim3((uint32_t)nseg), dim3(1024), 0, st, v, n, is_max, (uint64_t)SCAN_SEG, segtot);
+    hipLaunchKernelGGL(bzx_rl_scan_kernel, dim3(1), dim3(1024), 0, st, segtot, nseg, is_max, nseg, segtot + nseg);
+    hipLaunchKernelGGL(bzx_rl_scan_add_kernel, dim3((uint32_t)nseg), dim3(1024), 0, st, v, n, is_max, (uint64_t)SCAN_SEG,
+                       segtot, nseg);
 }
 
 // Emission analysis of my 32 bytes: e[i] in {0,1,2} packed 2 bits each; returns my emitted byte count.
@@ -225,42 +298,30 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_count_kernel(const uint8_t *__re
 {
     __shared__ uint64_t s64[RL_NT / 64];
     __shared__ uint32_t s32[RL_NT / 64];
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        // Cheap test first: a tile in which no four consecutive equal bytes end (looking 3 bytes back into the
-        // previous tile) has no run position k >= 3, so RLE1 copies it: emitted bytes = tile bytes.  The test
-        // may report a run that is not there (borrow in the zero-byte trick), never miss one.
-        if (tile > 0 && (tile + 1) * RL_TILE <= len) {
-            const uint64_t p0 = tile * RL_TILE + (uint64_t)threadIdx.x * RL_BYTES;
-            uint32_t w[9];
-            __builtin_memcpy(&w[0], raw + p0 - 4, 4);
-            const uint4 a = *reinterpret_cast<const uint4 *>(raw + p0);
-            const uint4 b = *reinterpret_cast<const uint4 *>(raw + p0 + 16);
-            w[1] = a.x; w[2] = a.y; w[3] = a.z; w[4] = a.w;
-            w[5] = b.x; w[6] = b.y; w[7] = b.z; w[8] = b.w;
-            uint64_t m = 0;                      // bit i: byte i of the 36 equals byte i+1
-#pragma unroll
-            for (int i = 0; i < 9; i++) {
-                const uint32_t nxt = i < 8 ? w[i + 1] : ~w[8];
-                const uint32_t z = w[i] ^ ((w[i] >> 8) | (nxt << 24));
-                const uint32_t f = ((z - 0x01010101u) & ~z & 0x80808080u) >> 7;      // 0x01 in every zero byte (or above one)
-                m |= (uint64_t)((f * 0x01020408u) >> 24 & 0xFu) << (4 * i);
-            }
-            m >>= 1;                             // pairs starting at byte p0-3 and later
-            const bool run4 = (m & (m >> 1) & (m >> 2)) != 0;
-            if (!__syncthreads_or(run4)) {
-                if (threadIdx.x == 0) {
-                    ws.tile_off[tile] = RL_TILE;
-                    ws.tile_np[tile] = 0;
-                }
-                continue;
-            }
+    // kernel A flagged the tiles that may hold a run position k >= 3; only those are analysed here.  A workgroup
+    // takes 256 tiles at a time (one flag per lane, coalesced) and walks the flagged ones.
+    __shared__ uint32_t s_list[RL_NT];
+    __shared__ uint32_t s_cnt;
+    for (uint64_t base = (uint64_t)blockIdx.x * RL_NT; base < ntiles; base += (uint64_t)gridDim.x * RL_NT) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        {
+            const uint64_t tile = base + threadIdx.x;
+            if (tile < ntiles && !(tile > 0 && (tile + 1) * RL_TILE <= len && ws.tile_np[tile] == 0))
+                s_list[atomicAdd(&s_cnt, 1u)] = threadIdx.x;
         }
-        TileInfo ti;
-        tile_analyse(raw, len, tile, ws, s64, s32, ti);
-        const bool np = __syncthreads_or(ti.any_long);
-        if (threadIdx.x == 0) {
-            ws.tile_off[tile] = ti.f_total;
-            ws.tile_np[tile] = np ? 1 : 0;
+        __syncthreads();
+        const uint32_t nlist = s_cnt;
+        for (uint32_t k = 0; k < nlist; k++) {
+            const uint64_t tile = base + s_list[k];
+            TileInfo ti;
+            tile_analyse(raw, len, tile, ws, s64, s32, ti);
+            const bool np = __syncthreads_or(ti.any_long);
+            if (threadIdx.x == 0) {
+                ws.tile_off[tile] = ti.f_total;
+                ws.tile_np[tile] = np ? 1 : 0;
+            }
+            __syncthreads();
         }
         __syncthreads();
     }
@@ -488,7 +549,8 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_scatter_kernel(const uint8_t *__
     __shared__ uint64_t s64[RL_NT / 64];
     __shared__ uint32_t s32[RL_NT / 64];
     const uint32_t nblk = ws.nblk[0];
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool all_plain = ws.tile_np[ntiles] == 0;      // no run position k >= 3 anywhere: every block is zero-copy
+    for (uint64_t tile = blockIdx.x; tile < ntiles && !all_plain; tile += gridDim.x) {
         {
             // skip tiles that lie entirely in blocks of other ranks or in zero-copy blocks (uniform decision)
             const uint64_t pa = tile * RL_TILE;
@@ -551,7 +613,7 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_scatter_kernel(const uint8_t *__
         __syncthreads();
     }
     for (uint32_t b = blockIdx.x * RL_NT + threadIdx.x; b < nblk; b += gridDim.x * RL_NT) {
-        blk[b].in_off = ws.blk_plain[b] ? (BZX_IN_RAW | ws.blk_raw[b]) : (uint64_t)b * BZX_BLK_STRIDE;
+        blk[b].in_off = (ws.blk_plain[b] || all_plain) ? (BZX_IN_RAW | ws.blk_raw[b]) : (uint64_t)b * BZX_BLK_STRIDE;
         blk[b].n = (uint32_t)(ws.blk_f[b + 1] - ws.blk_f[b]);
         blk[b].status = 0;
     }
@@ -698,7 +760,8 @@ int bzx_split_launch_boundaries(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, 
                                 BzxSplitWs *ws_out)
 {
     const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE;
-    const size_t bytes = (3 * (ntiles + 2) + 3 * ((size_t)max_blocks + 2)) * sizeof(uint64_t) + 64;
+    const uint64_t nsegw = ntiles / SCAN_SEG + 4;                         // scratch of the two-level scans
+    const size_t bytes = (3 * (ntiles + 2) + 3 * ((size_t)max_blocks + 2) + nsegw) * sizeof(uint64_t) + 64;
     void *p = nullptr;
     int rc = bzx_ctx_split_scratch(ctx, bytes, &p);
     if (rc) return rc;
@@ -710,15 +773,16 @@ int bzx_split_launch_boundaries(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, 
     ws.blk_f = ws.blk_raw + (max_blocks + 2);
     ws.blk_plain = (uint32_t *)(ws.blk_f + (max_blocks + 2));
     ws.nblk = (uint32_t *)((uint64_t *)ws.blk_plain + (max_blocks + 2));
+    uint64_t *segtot = (uint64_t *)ws.nblk + 8;
     ws.max_blocks = max_blocks;
     hipStream_t st = bzx_ctx_stream(ctx);
     const uint32_t grid = (uint32_t)(ntiles < (uint64_t)bzx_ctx_ncu(ctx) * 8 ? ntiles : (uint64_t)bzx_ctx_ncu(ctx) * 8);
     const uint32_t nmax = 100000u * (uint32_t)level - 19u;
     hipLaunchKernelGGL(bzx_rl_runstart_kernel, dim3(grid), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, ws);
-    hipLaunchKernelGGL(bzx_rl_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_rs, ntiles, 1);
+    launch_scan(st, ws.tile_rs, ntiles, 1, segtot);
     hipLaunchKernelGGL(bzx_rl_count_kernel, dim3(grid), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, ws);
-    hipLaunchKernelGGL(bzx_rl_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_off, ntiles, 0);
-    hipLaunchKernelGGL(bzx_rl_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_np, ntiles, 0);
+    launch_scan(st, ws.tile_off, ntiles, 0, segtot);
+    launch_scan(st, ws.tile_np, ntiles, 0, segtot);
     hipLaunchKernelGGL(bzx_rl_boundaries_kernel, dim3(1), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, nmax, ws);
     *ws_out = ws;
     return 0;
