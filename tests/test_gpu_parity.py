@@ -139,7 +139,7 @@ def test_large_roundtrip_properties(bzx, oracle):
     """Size-independent properties at a multi-hundred-block size (BASELINE configs[2] shape, scaled to keep the
     test short): libbz2 decodes the device stream back to the input; block count and framing are right; the first
     blocks are byte-identical to the oracle's stream of a prefix."""
-    n = 192 << 20
+    n = 272 << 20       # 317 blocks > 256 compute units: the sort's partial last round runs beside the MTF stage
     data = oracle.synthtext(n)
     out = bzx.compress_buffer(data, 9)
     st = bzx.stats()
@@ -151,6 +151,25 @@ def test_large_roundtrip_properties(bzx, oracle):
     assert nb == 9
     # the first 8 blocks end on a bit boundary; compare whole bytes safely inside them
     assert out[: len(ref) - 300_000] == ref[: len(ref) - 300_000]
+
+
+def test_deep_repeats(bzx, oracle):
+    """Highly redundant blocks (near-identical copies, fixed-size records): large groups that single symbols do
+    not separate are frozen and finished by prefix doubling; the stream must still be libbz2's bit for bit."""
+    import random
+    rnd = random.Random(5)
+    base = bytearray(oracle.synthtext(64000))
+    copies = bytearray()
+    for _ in range(14):                                  # 14 copies with ~0.5 % of the bytes changed
+        c = bytearray(base)
+        for _ in range(300):
+            c[rnd.randrange(len(c))] = rnd.randrange(256)
+        copies += c
+    rec = rnd.randbytes(190)
+    records = b"".join(rec + b"%010d" % (i * 7919) for i in range(4000))
+    twice = oracle.synthtext(440000) * 2 + b"tail"        # every rotation has a twin 440,000 bytes away
+    for data in (bytes(copies), records, twice, bytes(copies) + records[:200000]):
+        assert bzx.compress_buffer(data, 9) == bz2.compress(data, 9)
 
 
 def test_random_and_zero_heavy_inputs(bzx, oracle):
