@@ -48,6 +48,9 @@
 // TEXT records of a group that the symbol-wise splitter gave up on (deep repeats inside a large group): the
 // group is left alone by the tile rounds and resolved by prefix doubling (RANK rounds) afterwards
 #define TXT_FROZEN (1ull << 38)
+// RANK records: same idea for one round (a large group whose members all have the same key2 cannot be refined
+// in this round): bit 0 of the record (bits 0..3 are free)
+#define RNK_FROZEN 1ull
 
 __shared__ uint32_t s_hist[5][256];
 __shared__ uint32_t s_base[256];
@@ -420,41 +423,6 @@ __device__ __attribute__((noinline)) void isa_build(const uint32_t *__restrict__
     }
 }
 
-// key2 = rank of the rotation h positions further on; fills the five digit histograms.
-__device__ __attribute__((noinline)) void gather_keys(uint64_t *__restrict__ U, uint32_t m, const uint32_t *__restrict__ ISA, uint32_t n,
-                            uint32_t h)
-{
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < 5 * 256; i += SORT_NT) (&s_hist[0][0])[i] = 0;
-    __syncthreads();
-    for (uint32_t t0 = 0; t0 < m; t0 += SORT_NT * SORT_E) {
-        uint64_t rec[SORT_E];
-        uint32_t key2[SORT_E];
-#pragma unroll
-        for (int e = 0; e < SORT_E; e++) {
-            const uint32_t k = t0 + e * SORT_NT + tid;
-            rec[e] = k < m ? U[k] : 0ull;
-        }
-#pragma unroll
-        for (int e = 0; e < SORT_E; e++) {
-            const uint32_t k = t0 + e * SORT_NT + tid;
-            uint32_t p = ((uint32_t)(rec[e] >> RNK_SA_SHIFT) & 0xFFFFFu) + h;
-            if (p >= n) p -= n;
-            key2[e] = k < m ? ISA[p] : 0u;
-        }
-#pragma unroll
-        for (int e = 0; e < SORT_E; e++) {
-            const uint32_t k = t0 + e * SORT_NT + tid;
-            const bool valid = k < m;
-            const uint64_t x = rec[e] | ((uint64_t)key2[e] << RNK_KEY_SHIFT);
-            if (valid) U[k] = x;
-#pragma unroll
-            for (int p = 0; p < 5; p++) hist_add(s_hist[p], (uint32_t)(x >> (RNK_KEY_SHIFT + 8 * p)) & 255u, valid);
-        }
-    }
-    __syncthreads();
-}
-
 // ---- tile rounds: every group fits one wave tile ---------------------------------------------------
 // When the largest group has <= SEG_T members a refinement round needs no global radix passes: each
 // wave walks its share of the compacted records in tiles of SEG_T (8 per lane) cut at group boundaries,
@@ -523,7 +491,7 @@ __device__ __forceinline__ uint32_t seg_align(const uint64_t *__restrict__ U, ui
 {
     if (r0 == 0) return 0;
     if (r0 >= m) return m;
-    if (TEXT && (U[r0] & TXT_FROZEN)) return r0;      // a frozen group may be cut anywhere: the round skips it
+    if (U[r0] & (TEXT ? TXT_FROZEN : RNK_FROZEN)) return r0;      // a frozen group may be cut anywhere: the round skips it
     uint32_t best = 0xffffffffu;
 #pragma unroll
     for (int j = 0; j < SEG_PER_LANE; j++) {
@@ -563,10 +531,11 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
             v[j].rec = i < lim ? U[i] : ~0ull;
             v[j].key = 0;
         }
-        if (TEXT) {
+        constexpr uint64_t FROZEN = TEXT ? TXT_FROZEN : RNK_FROZEN;
+        {
             // frozen group at the tile start: skip to its end (the first boundary in the tile) without sorting
             const uint64_t first = __shfl(v[0].rec, 0);
-            if (first & TXT_FROZEN) {
+            if (first & FROZEN) {
                 const uint64_t after = __shfl_down(v[0].rec, 1);
                 uint32_t fb = lim;
 #pragma unroll
@@ -585,7 +554,7 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
             }
         }
         // b = last group boundary in (a, lim]  (lim == end is a boundary, unless a frozen group was cut there)
-        const bool tail_frozen = TEXT && lim == end && (U[lim - 1] & TXT_FROZEN);
+        const bool tail_frozen = lim == end && (U[lim - 1] & FROZEN);
         uint32_t b = lim;
         if (lim != end || tail_frozen) {
             uint64_t after = __shfl_down(v[0].rec, 1);      // first record of the next lane
@@ -709,6 +678,7 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
 __shared__ uint32_t s_big[5];     // [0] groups in the current list, [1] in the next list, [2] overflow flag,
                                   // [3] rotations in the current list's groups, [4] in the next list's groups
 
+template <bool TEXT>
 __device__ __attribute__((noinline)) void big_find(const uint64_t *__restrict__ U, const uint32_t *__restrict__ S,
                                                     uint32_t m, uint32_t *__restrict__ list)
 {
@@ -727,7 +697,7 @@ __device__ __attribute__((noinline)) void big_find(const uint64_t *__restrict__ 
         const bool is_end = (k + 1 == m) || ((uint32_t)(U[k + 1] >> G_SHIFT) != g);
         if (is_end) {
             const uint32_t size = S[k] - g + 1;        // slots of a group are consecutive SA positions
-            if (size > SEG_T_TEXT && !(rec & TXT_FROZEN)) {
+            if (size > (TEXT ? SEG_T_TEXT : SEG_T) && !(TEXT && (rec & TXT_FROZEN))) {
                 const uint32_t idx = atomicAdd(&s_big[0], 1u);
                 atomicAdd(&s_big[3], size);
                 if (idx < BIG_MAX) {
@@ -742,11 +712,29 @@ __device__ __attribute__((noinline)) void big_find(const uint64_t *__restrict__ 
     __syncthreads();
 }
 
+// digit of a record for the split pass.  TEXT: dense id of the symbol d places into the rotation.  RANK: 8 bits
+// (pass 0, 1) or 4 bits (pass 2) of key2 = rank of the rotation h places on, most significant first.
+template <bool TEXT>
+__device__ __forceinline__ uint32_t big_digit(uint64_t rec, const uint8_t *__restrict__ T,
+                                              const uint32_t *__restrict__ ISA, uint32_t n, uint32_t dmod, uint32_t pass)
+{
+    uint32_t p = ((uint32_t)(rec >> (TEXT ? TXT_SA_SHIFT : RNK_SA_SHIFT)) & 0xFFFFFu) + dmod;
+    if (p >= n) p -= n;
+    if (TEXT) return s_seq[T[p]];
+    const uint32_t r = ISA[p];
+    return pass == 0 ? (r >> 12) & 255u : pass == 1 ? (r >> 4) & 255u : r & 15u;
+}
+
+// d: TEXT symbol index / RANK distance h.  pass: RANK digit selector.
+template <bool TEXT>
 __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ U, uint64_t *__restrict__ Utmp,
                                                           const uint32_t *__restrict__ list, uint32_t nlist,
                                                           uint32_t *__restrict__ next, const uint8_t *__restrict__ T,
-                                                          uint32_t n, uint32_t d)
+                                                          const uint32_t *__restrict__ ISA, uint32_t n, uint32_t d,
+                                                          uint32_t pass)
 {
+    constexpr uint32_t BIG = TEXT ? SEG_T_TEXT : SEG_T;
+    constexpr uint64_t LOW = TEXT ? ((1ull << TXT_KEY_SHIFT) - 1ull) : 0xFFFFF0ull;     // sa (| prev), slot / flags cleared
     const uint32_t lane = bzx_lane(), wave = bzx_wave();
     uint32_t *hist = &s_wcnt[0][wave * 256];     // counts, then bucket bases
     uint32_t *cur = &s_wcnt[1][wave * 256];      // scatter cursors
@@ -758,9 +746,7 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
         bzx_wave_sync();
         const uint32_t g0 = (uint32_t)(U[ks] >> G_SHIFT);
         for (uint32_t o = lane; o < size; o += 64) {
-            uint32_t p = ((uint32_t)(U[ks + o] >> TXT_SA_SHIFT) & 0xFFFFFu) + dmod;
-            if (p >= n) p -= n;
-            atomicAdd(&hist[s_seq[T[p]]], 1u);
+            atomicAdd(&hist[big_digit<TEXT>(U[ks + o], T, ISA, n, dmod, pass)], 1u);
         }
         bzx_wave_sync();
         // exclusive scan of the 256 counts: 4 digits per lane
@@ -775,7 +761,7 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
         for (int i = 0; i < 4; i++) {
             hist[4 * lane + i] = run;
             cur[4 * lane + i] = run;
-            if (c[i] > SEG_T_TEXT) {
+            if (c[i] > BIG) {
                 atomicAdd(&s_big[4], c[i]);
                 const uint32_t idx = atomicAdd(&s_big[1], 1u);
                 if (idx < BIG_MAX) {
@@ -790,12 +776,9 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
         bzx_wave_sync();
         for (uint32_t o = lane; o < size; o += 64) {
             const uint64_t rec = U[ks + o];
-            uint32_t p = ((uint32_t)(rec >> TXT_SA_SHIFT) & 0xFFFFFu) + dmod;
-            if (p >= n) p -= n;
-            const uint32_t dg = s_seq[T[p]];
+            const uint32_t dg = big_digit<TEXT>(rec, T, ISA, n, dmod, pass);
             const uint32_t pos = atomicAdd(&cur[dg], 1u);
-            const uint64_t low = rec & ((1ull << TXT_KEY_SHIFT) - 1ull);          // sa | prev, tile slot cleared
-            Utmp[ks + pos] = ((uint64_t)(g0 + hist[dg]) << G_SHIFT) | low;
+            Utmp[ks + pos] = ((uint64_t)(g0 + hist[dg]) << G_SHIFT) | (rec & LOW);
         }
         // all lanes' stores must have landed before the wave reads the range back
 #ifndef BZX_HIP_EMU
@@ -817,9 +800,7 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
             __syncthreads();
             const uint32_t g0 = (uint32_t)(U[ks] >> G_SHIFT);
             for (uint32_t o = tid; o < size; o += SORT_NT) {
-                uint32_t p = ((uint32_t)(U[ks + o] >> TXT_SA_SHIFT) & 0xFFFFFu) + dmod;
-                if (p >= n) p -= n;
-                atomicAdd(&bh[s_seq[T[p]]], 1u);
+                atomicAdd(&bh[big_digit<TEXT>(U[ks + o], T, ISA, n, dmod, pass)], 1u);
             }
             __syncthreads();
             uint32_t tot;
@@ -828,7 +809,7 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
             if (tid < 256) {
                 bh[tid] = base;
                 bc[tid] = base;
-                if (cnt > SEG_T_TEXT) {
+                if (cnt > BIG) {
                     atomicAdd(&s_big[4], cnt);
                     const uint32_t idx = atomicAdd(&s_big[1], 1u);
                     if (idx < BIG_MAX) {
@@ -842,12 +823,9 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
             __syncthreads();
             for (uint32_t o = tid; o < size; o += SORT_NT) {
                 const uint64_t rec = U[ks + o];
-                uint32_t p = ((uint32_t)(rec >> TXT_SA_SHIFT) & 0xFFFFFu) + dmod;
-                if (p >= n) p -= n;
-                const uint32_t dg = s_seq[T[p]];
+                const uint32_t dg = big_digit<TEXT>(rec, T, ISA, n, dmod, pass);
                 const uint32_t pos = atomicAdd(&bc[dg], 1u);
-                const uint64_t low = rec & ((1ull << TXT_KEY_SHIFT) - 1ull);
-                Utmp[ks + pos] = ((uint64_t)(g0 + bh[dg]) << G_SHIFT) | low;
+                Utmp[ks + pos] = ((uint64_t)(g0 + bh[dg]) << G_SHIFT) | (rec & LOW);
             }
             __syncthreads();
             for (uint32_t o = tid; o < size; o += SORT_NT) U[ks + o] = Utmp[ks + o];
@@ -856,18 +834,25 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
     }
 }
 
-// Splits every group with more than SEG_T_TEXT members by single symbols until it fits a tile.  Groups that single
-// symbols separate too slowly (deep repeats: two passes in a row that leave >88 % of the listed rotations in
-// oversized groups, or a work budget of 4 n rotation-passes) are FROZEN: flagged in their records, skipped by the
-// tile rounds and resolved by prefix doubling later.  Returns 0 when every group fits a tile now, else the number
-// of symbols (>= depth) that all frozen groups are known to agree on.
+// Splits every group that does not fit a wave tile until it does.
+// TEXT: by single symbols (symbol depth, depth+1, ...).  Groups that single symbols separate too slowly (deep
+//   repeats: two passes in a row that leave >88 % of the listed rotations in oversized groups, or a work budget of
+//   4 n rotation-passes) are FROZEN: flagged in their records, skipped by the tile rounds and resolved by prefix
+//   doubling later.  Returns 0 when every group fits a tile now, else the number of symbols (>= depth) that all
+//   frozen groups are known to agree on.
+// RANK (d = h): by key2 = ISA[(sa + h) mod n], most significant digit first, at most three passes (8 + 8 + 4
+//   bits); sub-groups come out ordered by key2 and the tile sort finishes them.  What is still oversized after
+//   the last digit has one key2 throughout: this round cannot refine it, it is flagged RNK_FROZEN for the round.
+template <bool TEXT>
 __device__ __attribute__((noinline)) uint32_t big_split(uint64_t *__restrict__ U, uint64_t *__restrict__ Utmp,
                                                          const uint32_t *__restrict__ S, uint32_t m,
                                                          uint32_t *__restrict__ scratch, const uint8_t *__restrict__ T,
-                                                         uint32_t n, uint32_t depth)
+                                                         const uint32_t *__restrict__ ISA, uint32_t n, uint32_t d)
 {
+    constexpr uint32_t BIG = TEXT ? SEG_T_TEXT : SEG_T;
+    constexpr uint64_t FROZEN = TEXT ? TXT_FROZEN : RNK_FROZEN;
     uint32_t *la = scratch, *lb = scratch + 2 * BIG_MAX;
-    big_find(U, S, m, la);
+    big_find<TEXT>(U, S, m, la);
     uint32_t stall = 0, pass = 0;
     uint64_t work = 0;
     for (;; pass++) {
@@ -875,8 +860,8 @@ __device__ __attribute__((noinline)) uint32_t big_split(uint64_t *__restrict__ U
         __syncthreads();
         if (nlist == 0 && !ovf) return 0;
         work += before;
-        if (ovf || pass >= BIG_PASSES || stall >= 2 || work > 4ull * n) break;
-        big_split_pass(U, Utmp, la, nlist, lb, T, n, depth + pass);
+        if (TEXT ? (ovf || pass >= BIG_PASSES || stall >= 2 || work > 4ull * n) : (ovf || pass >= 3)) break;
+        big_split_pass<TEXT>(U, Utmp, la, nlist, lb, T, ISA, n, TEXT ? d + pass : d, pass);
         const uint32_t after = s_big[4];
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -892,20 +877,20 @@ __device__ __attribute__((noinline)) uint32_t big_split(uint64_t *__restrict__ U
         lb = t;
     }
     // freeze what is still oversized: the member at offset o of a group (slots are consecutive, so o = S[k] - g)
-    // belongs to a group of more than SEG_T_TEXT rotations iff the record SEG_T_TEXT - o places on has the same g
+    // belongs to a group of more than BIG rotations iff the record BIG - o places on has the same g
     for (uint32_t k = threadIdx.x; k < m; k += SORT_NT) {
         const uint64_t rec = U[k];
-        if (rec & TXT_FROZEN) continue;
+        if (rec & FROZEN) continue;
         const uint32_t g = (uint32_t)(rec >> G_SHIFT), off = S[k] - g;
-        bool big = off >= SEG_T_TEXT;
+        bool big = off >= BIG;
         if (!big) {
-            const uint32_t j = k + (SEG_T_TEXT - off);
+            const uint32_t j = k + (BIG - off);
             big = j < m && (uint32_t)(U[j] >> G_SHIFT) == g;
         }
-        if (big) U[k] = rec | TXT_FROZEN;
+        if (big) U[k] = rec | FROZEN;
     }
     __syncthreads();
-    return depth + pass;        // every listed group was split by the symbols depth .. depth+pass-1
+    return d + pass;        // TEXT: every listed group was split by the symbols depth .. depth+pass-1
 }
 
 // diagnostic phase timers (B.dbg != null only in profiling runs): accumulate wall-clock ticks per phase
@@ -994,7 +979,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
             const uint32_t maxgrp = s_bcast[3];
             __syncthreads();
             if (maxgrp > SEG_T_TEXT) {
-                const uint32_t fr = big_split(ua, ub, sa_cur, m, ws.isa, T, n, depth);
+                const uint32_t fr = big_split<true>(ua, ub, sa_cur, m, ws.isa, T, nullptr, n, depth);
                 PHASE_STAMP(10 + (round < 7 ? round : 7) * 3);
                 if (fr && fr < frozen_depth) frozen_depth = fr;           // frozen groups agree on >= fr symbols
             }
@@ -1031,32 +1016,31 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
             PHASE_STAMP(5);
             // every unresolved group agrees on at least h symbols (frozen groups stopped at an earlier depth)
             uint32_t h = depth < frozen_depth ? depth : frozen_depth, rround = 0;
-            bool force_global = frozen_depth != 0xffffffffu;     // the last TEXT rerank did not measure frozen groups
+            bool unmeasured = frozen_depth != 0xffffffffu;       // the last TEXT rerank did not measure frozen groups
             while (m > 0 && h < n) {
-                const uint32_t maxgrp = force_global ? 0xFFFFFu : s_bcast[3];
-                force_global = false;
+                const uint32_t maxgrp = unmeasured ? 0xFFFFFu : s_bcast[3];
+                unmeasured = false;
                 __syncthreads();
                 if (B.dbg && tid == 0) {       // diagnostics: unresolved rotations / largest group entering RANK round r
                     atomicAdd(&B.dbg[52 + (rround < 5 ? rround : 5) * 2], (unsigned long long)m);
                     atomicAdd(&B.dbg[53 + (rround < 5 ? rround : 5) * 2], (unsigned long long)maxgrp);
                 }
                 rround++;
-                if (maxgrp <= SEG_T) {
-                    seg_sort_round<false, 8>(ua, m, ws.isa, T, n, h);
-                    m = rerank<MODE_RANK>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out, T, n);
+                // groups larger than a tile are first split by the digits of key2 (counting sorts inside the
+                // group's own range; the scratch lists live in the slot map that the next rerank overwrites)
+                if (maxgrp > SEG_T) {
+                    (void)big_split<false>(ua, ub, sa_cur, m, sa_alt, T, ws.isa, n, h % n);
+                    PHASE_STAMP(7);
+                }
+                seg_sort_round<false, 8>(ua, m, ws.isa, T, n, h);
+                PHASE_STAMP(6);
+                m = rerank<MODE_RANK>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out, T, n);
+                {
                     uint64_t *tu = ua; ua = ub; ub = tu;
-                } else {
-                    gather_keys(ua, m, ws.isa, n, h);
-                    // five passes: ua -> ub -> ua -> ub -> ua -> ub
-                    radix_pass<SRC_REC>(ua, ub, m, RNK_KEY_SHIFT, s_hist[0]);
-                    radix_pass<SRC_REC>(ub, ua, m, RNK_KEY_SHIFT + 8, s_hist[1]);
-                    radix_pass<SRC_REC>(ua, ub, m, RNK_KEY_SHIFT + 16, s_hist[2]);
-                    radix_pass<SRC_REC>(ub, ua, m, RNK_KEY_SHIFT + 24, s_hist[3]);
-                    radix_pass<SRC_REC>(ua, ub, m, RNK_KEY_SHIFT + 32, s_hist[4]);
-                    m = rerank<MODE_RANK>(ub, sa_cur, m, ua, sa_alt, ws.isa, ws.sa, L, orig_out, T, n);
                 }
                 uint32_t *ts = sa_cur; sa_cur = sa_alt; sa_alt = ts;
                 h <<= 1;
+                PHASE_STAMP(4);
             }
             // rotations still tied (periodic block): their rows of L are tie-invariant, write them now
             for (uint32_t k = tid; k < m; k += SORT_NT) {

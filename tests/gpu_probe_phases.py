@@ -24,7 +24,7 @@ lib._check(L.bzx_dbg_time_stages(lib.ctx, blk, len(blk), reps, 1, ms))
 lib._check(L.bzx_dbg_phase_timers(lib.ctx, 1, None))
 lib._check(L.bzx_dbg_time_stages(lib.ctx, blk, len(blk), reps, 15, ms))
 lib._check(L.bzx_dbg_phase_timers(lib.ctx, 0, t))
-names = {4: "RANK rounds", 5: "ISA build", 48: "EMIT load tables + header", 49: "EMIT selectors", 50: "EMIT coding tables", 51: "EMIT payload", 40: "HUF init tables", 41: "HUF cost+rfreq passes (x4)", 42: "HUF code lengths (x4)", 43: "HUF codes+store", 44: "HUF payload sizes", 45: "HUF selector MTF", 32: "MTF in-use", 33: "MTF recency lists", 34: "MTF start lists", 35: "MTF ranks", 36: "MTF zero-run + emit", 0: "I1 build", 1: "I2 4 radix passes", 2: "R0 rerank", 3: "F final gather"}
+names = {4: "RANK re-rank (ISA scatter)", 6: "RANK tile sorts (ISA gather)", 7: "RANK big-group split (key2 digits)", 5: "ISA build", 48: "EMIT load tables + header", 49: "EMIT selectors", 50: "EMIT coding tables", 51: "EMIT payload", 40: "HUF init tables", 41: "HUF cost+rfreq passes (x4)", 42: "HUF code lengths (x4)", 43: "HUF codes+store", 44: "HUF payload sizes", 45: "HUF selector MTF", 32: "MTF in-use", 33: "MTF recency lists", 34: "MTF start lists", 35: "MTF ranks", 36: "MTF zero-run + emit", 0: "I1 build", 1: "I2 4 radix passes", 2: "R0 rerank", 3: "F final gather"}
 for r in range(8):
     names[8 + 3 * r] = f"round{r} seg sort"; names[9 + 3 * r] = f"round{r} rerank"; names[10 + 3 * r] = f"round{r} big-group split"
 cnt = list(t[52:64])
