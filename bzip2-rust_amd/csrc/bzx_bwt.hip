@@ -51,6 +51,8 @@
 // RANK records: same idea for one round (a large group whose members all have the same key2 cannot be refined
 // in this round): bit 0 of the record (bits 0..3 are free)
 #define RNK_FROZEN 1ull
+// RANK records whose group start was changed by the digit splitter since the last rerank (their ISA entry is stale)
+#define RNK_MOVED 2ull
 
 __shared__ uint32_t s_hist[5][256];
 __shared__ uint32_t s_base[256];
@@ -364,12 +366,14 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
                 const uint32_t newrank = INITIAL ? kstart : S[kstart];
                 const uint32_t sa = (uint32_t)(rec >> SA_SHIFT) & 0xFFFFFu;
                 const uint32_t pos = INITIAL ? k : S[k];
-                SA[pos] = sa;
                 if (MODE == MODE_RANK) {
-                    ISA[sa] = newrank;
+                    // (the suffix array itself is not needed any more: it only seeds the ISA when RANK mode starts;
+                    // the rank of a rotation changes only when its group was split)
+                    if (newrank != (uint32_t)(rec >> G_SHIFT) || (rec & RNK_MOVED)) ISA[sa] = newrank;
                     // RANK records carry no preceding byte: fetch it once, when the rotation's row is final
                     if (f[j] && f[j + 1]) L[pos] = T[sa ? sa - 1 : n - 1];
                 } else {
+                    SA[pos] = sa;
                     L[pos] = (uint8_t)rec;
                 }
                 if (sa == 0) *orig_out = pos;
@@ -713,15 +717,19 @@ __device__ __attribute__((noinline)) void big_find(const uint64_t *__restrict__ 
 }
 
 // digit of a record for the split pass.  TEXT: dense id of the symbol d places into the rotation.  RANK: 8 bits
-// (pass 0, 1) or 4 bits (pass 2) of key2 = rank of the rotation h places on, most significant first.
-template <bool TEXT>
-__device__ __forceinline__ uint32_t big_digit(uint64_t rec, const uint8_t *__restrict__ T,
+// (pass 0, 1) or 4 bits (pass 2) of key2 = rank of the rotation h places on, most significant first; key2 is
+// fetched once, by the counting sweep of pass 0 (FETCH), and travels in the record's key2 field afterwards.
+template <bool TEXT, bool FETCH>
+__device__ __forceinline__ uint32_t big_digit(uint64_t &rec, const uint8_t *__restrict__ T,
                                               const uint32_t *__restrict__ ISA, uint32_t n, uint32_t dmod, uint32_t pass)
 {
-    uint32_t p = ((uint32_t)(rec >> (TEXT ? TXT_SA_SHIFT : RNK_SA_SHIFT)) & 0xFFFFFu) + dmod;
-    if (p >= n) p -= n;
-    if (TEXT) return s_seq[T[p]];
-    const uint32_t r = ISA[p];
+    if (TEXT || FETCH) {
+        uint32_t p = ((uint32_t)(rec >> (TEXT ? TXT_SA_SHIFT : RNK_SA_SHIFT)) & 0xFFFFFu) + dmod;
+        if (p >= n) p -= n;
+        if (TEXT) return s_seq[T[p]];
+        rec |= (uint64_t)ISA[p] << RNK_KEY_SHIFT;
+    }
+    const uint32_t r = (uint32_t)(rec >> RNK_KEY_SHIFT) & 0xFFFFFu;
     return pass == 0 ? (r >> 12) & 255u : pass == 1 ? (r >> 4) & 255u : r & 15u;
 }
 
@@ -734,7 +742,8 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
                                                           uint32_t pass)
 {
     constexpr uint32_t BIG = TEXT ? SEG_T_TEXT : SEG_T;
-    constexpr uint64_t LOW = TEXT ? ((1ull << TXT_KEY_SHIFT) - 1ull) : 0xFFFFF0ull;     // sa (| prev), slot / flags cleared
+    constexpr uint64_t LOW = TEXT ? ((1ull << TXT_KEY_SHIFT) - 1ull)                  // sa | prev, tile slot cleared
+                                  : ((1ull << G_SHIFT) - 16ull) | RNK_MOVED;           // key2 | sa, frozen flag cleared
     const uint32_t lane = bzx_lane(), wave = bzx_wave();
     uint32_t *hist = &s_wcnt[0][wave * 256];     // counts, then bucket bases
     uint32_t *cur = &s_wcnt[1][wave * 256];      // scatter cursors
@@ -746,7 +755,13 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
         bzx_wave_sync();
         const uint32_t g0 = (uint32_t)(U[ks] >> G_SHIFT);
         for (uint32_t o = lane; o < size; o += 64) {
-            atomicAdd(&hist[big_digit<TEXT>(U[ks + o], T, ISA, n, dmod, pass)], 1u);
+            uint64_t rec = U[ks + o];
+            if (!TEXT && pass == 0) {
+                atomicAdd(&hist[big_digit<TEXT, true>(rec, T, ISA, n, dmod, pass)], 1u);
+                U[ks + o] = rec;                  // key2 stays in the record for the sweeps that follow
+            } else {
+                atomicAdd(&hist[big_digit<TEXT, false>(rec, T, ISA, n, dmod, pass)], 1u);
+            }
         }
         bzx_wave_sync();
         // exclusive scan of the 256 counts: 4 digits per lane
@@ -775,10 +790,10 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
         }
         bzx_wave_sync();
         for (uint32_t o = lane; o < size; o += 64) {
-            const uint64_t rec = U[ks + o];
-            const uint32_t dg = big_digit<TEXT>(rec, T, ISA, n, dmod, pass);
+            uint64_t rec = U[ks + o];
+            const uint32_t dg = big_digit<TEXT, false>(rec, T, ISA, n, dmod, pass);
             const uint32_t pos = atomicAdd(&cur[dg], 1u);
-            Utmp[ks + pos] = ((uint64_t)(g0 + hist[dg]) << G_SHIFT) | (rec & LOW);
+            Utmp[ks + pos] = ((uint64_t)(g0 + hist[dg]) << G_SHIFT) | (rec & LOW) | ((!TEXT && hist[dg]) ? RNK_MOVED : 0ull);
         }
         // all lanes' stores must have landed before the wave reads the range back
 #ifndef BZX_HIP_EMU
@@ -800,7 +815,13 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
             __syncthreads();
             const uint32_t g0 = (uint32_t)(U[ks] >> G_SHIFT);
             for (uint32_t o = tid; o < size; o += SORT_NT) {
-                atomicAdd(&bh[big_digit<TEXT>(U[ks + o], T, ISA, n, dmod, pass)], 1u);
+                uint64_t rec = U[ks + o];
+                if (!TEXT && pass == 0) {
+                    atomicAdd(&bh[big_digit<TEXT, true>(rec, T, ISA, n, dmod, pass)], 1u);
+                    U[ks + o] = rec;
+                } else {
+                    atomicAdd(&bh[big_digit<TEXT, false>(rec, T, ISA, n, dmod, pass)], 1u);
+                }
             }
             __syncthreads();
             uint32_t tot;
@@ -822,10 +843,10 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
             }
             __syncthreads();
             for (uint32_t o = tid; o < size; o += SORT_NT) {
-                const uint64_t rec = U[ks + o];
-                const uint32_t dg = big_digit<TEXT>(rec, T, ISA, n, dmod, pass);
+                uint64_t rec = U[ks + o];
+                const uint32_t dg = big_digit<TEXT, false>(rec, T, ISA, n, dmod, pass);
                 const uint32_t pos = atomicAdd(&bc[dg], 1u);
-                Utmp[ks + pos] = ((uint64_t)(g0 + bh[dg]) << G_SHIFT) | (rec & LOW);
+                Utmp[ks + pos] = ((uint64_t)(g0 + bh[dg]) << G_SHIFT) | (rec & LOW) | ((!TEXT && bh[dg]) ? RNK_MOVED : 0ull);
             }
             __syncthreads();
             for (uint32_t o = tid; o < size; o += SORT_NT) U[ks + o] = Utmp[ks + o];
