@@ -19,7 +19,7 @@
 #define MTF_E 16
 
 __shared__ __attribute__((aligned(16))) uint8_t m_rec[MTF_LIST_BYTES];    // per-chunk recency lists (most recent first)
-__shared__ __attribute__((aligned(16))) uint8_t m_list[MTF_LIST_BYTES];   // per-chunk working MTF lists
+__shared__ __attribute__((aligned(16))) uint8_t m_list[MTF_LIST_BYTES + 32];   // per-chunk working MTF lists (+ read slack of the 4-word walk)
 __shared__ uint16_t m_reccnt[MTF_NT];
 #define MTF_GROUP 32                                   // chunks per group of the two-level start-list walk
 __shared__ uint8_t m_super[(MTF_NT / MTF_GROUP) * 264];   // recency list of every group of 32 chunks
@@ -300,24 +300,37 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
                                     w = (w & himask) | ((w & lowmask) << 8) | s;
                                 }
                             } else {
+                                // deeper than the front word: walk the LDS list four words (32 entries) per step so
+                                // that a deep hit costs a quarter of the dependent LDS round trips; words in front
+                                // of the hit are shifted by one entry on the way (reads past my list's last word
+                                // see the neighbour's list or padding, but the symbol is always found before them)
                                 uint64_t carry = w >> 56;
                                 w = (w << 8) | s;
                                 uint32_t qq = 1;
                                 for (;;) {
-                                    const uint64_t c = lst64[qq];
-                                    x = c ^ sp;
-                                    z = (x - ones) & ~x & highs;
-                                    if (z) {
-                                        const uint32_t j = (uint32_t)(__ffsll((unsigned long long)z) - 1) >> 3;
-                                        const uint64_t lowmask = j ? ((1ull << (8 * j)) - 1ull) : 0ull;
-                                        const uint64_t himask = j == 7 ? 0ull : (~0ull << (8 * (j + 1)));
-                                        lst64[qq] = (c & himask) | ((c & lowmask) << 8) | carry;
-                                        rank = 8 * qq + j;
-                                        break;
+                                    const uint64_t c0 = lst64[qq], c1 = lst64[qq + 1], c2 = lst64[qq + 2], c3 = lst64[qq + 3];
+                                    const uint64_t x0 = c0 ^ sp, x1 = c1 ^ sp, x2 = c2 ^ sp, x3 = c3 ^ sp;
+                                    const uint64_t z0 = (x0 - ones) & ~x0 & highs, z1 = (x1 - ones) & ~x1 & highs;
+                                    const uint64_t z2 = (x2 - ones) & ~x2 & highs, z3 = (x3 - ones) & ~x3 & highs;
+                                    const uint32_t hk = z0 ? 0u : z1 ? 1u : z2 ? 2u : z3 ? 3u : 4u;
+                                    if (hk > 0) lst64[qq] = (c0 << 8) | carry;
+                                    if (hk > 1) lst64[qq + 1] = (c1 << 8) | (c0 >> 56);
+                                    if (hk > 2) lst64[qq + 2] = (c2 << 8) | (c1 >> 56);
+                                    if (hk > 3) {
+                                        lst64[qq + 3] = (c3 << 8) | (c2 >> 56);
+                                        carry = c3 >> 56;
+                                        qq += 4;
+                                        continue;
                                     }
-                                    lst64[qq] = (c << 8) | carry;
-                                    carry = c >> 56;
-                                    qq++;
+                                    const uint64_t ch = hk == 0 ? c0 : hk == 1 ? c1 : hk == 2 ? c2 : c3;
+                                    const uint64_t zh = hk == 0 ? z0 : hk == 1 ? z1 : hk == 2 ? z2 : z3;
+                                    const uint64_t cin = hk == 0 ? carry : (hk == 1 ? c0 : hk == 2 ? c1 : c2) >> 56;
+                                    const uint32_t j = (uint32_t)(__ffsll((unsigned long long)zh) - 1) >> 3;
+                                    const uint64_t lowmask = j ? ((1ull << (8 * j)) - 1ull) : 0ull;
+                                    const uint64_t himask = j == 7 ? 0ull : (~0ull << (8 * (j + 1)));
+                                    lst64[qq + hk] = (ch & himask) | ((ch & lowmask) << 8) | cin;
+                                    rank = 8 * (qq + hk) + j;
+                                    break;
                                 }
                             }
                             o[q] |= rank << (8 * k);
