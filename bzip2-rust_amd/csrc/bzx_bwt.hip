@@ -6,24 +6,26 @@
 // (sais_fallback.rs:469-578); neither maps to a GPU.  Here one workgroup (1024 lanes) sorts one
 // block, keeping only the rotations that are still tied ("unresolved") from round to round:
 //
-//   I1  records [first 4 bytes:32 | i:20 | preceding byte:8], 4 digit histograms          (n)
-//   I2  4 stable LSD radix passes (8-bit digits, wave64 match-any ranking, LDS offsets)   (n each)
+//   A   bytes in use -> dense symbol ids of `bits` bits (a 32-bit key then holds ksym symbols plus the top
+//       bits of the next one; a 64-bit round key holds csym symbols)
+//   I   records [key:32 | i:20 | preceding byte:8], built from the block by the first of four stable
+//       8-bit LSD radix passes (per-wave LDS digit masks and counters, LDS-staged coalesced scatter)     (n each)
 //   R   re-rank: group boundaries, SA[pos] = sa, L[pos] = preceding byte, compaction of the
-//       rotations in groups of size > 1 to records [group start g:20 | .. | sa:20 | prev:8] (m)
-//   TEXT rounds (depth 4, 12, 20, 28; while every group has <= 512 members):
-//       each wave sorts tiles of <= 512 records, cut at group boundaries, by (g, next 8 text
-//       bytes at sa+depth) with a register / cross-lane bitonic network; the tile-local start of
-//       every new group is stored in the record so R sees the new boundaries.  No ISA exists in
-//       this mode: the only random accesses are 8-byte reads of the 900 KB block itself.     (m)
-//   RANK rounds (only for deep repeats / large groups; h doubles): ISA is built once from SA,
-//       then key2 = ISA[(sa+h) mod n]; tiles as above when groups are small, else five global
-//       LSD passes over [g:20 | key2:20 | sa:20]; R also maintains ISA.                      (m)
-//   F   (RANK mode only) L[j] = T[SA[j]-1], orig_ptr
+//       rotations in groups of size > 1 to records [group start g:20 | .. | sa:20 | prev:8]             (m)
+//   TEXT rounds (csym symbols deeper each):
+//       groups larger than a tile are split by single symbols (counting sorts inside the group's range);
+//       groups that resist are FROZEN for the RANK rounds; then each wave sorts tiles of <= 256 records,
+//       cut at group boundaries, by (g, next csym symbols at sa+depth) with a register / cross-lane
+//       bitonic network.  No ISA exists in this mode: the only random accesses are 16-byte reads of the
+//       block itself.                                                                                    (m)
+//   RANK rounds (only for deep repeats; h doubles): ISA is built once from SA (radix pass + LDS windows),
+//       key2 = ISA[(sa+h) mod n]; oversized groups are split by the digits of key2, wave tiles of <= 512
+//       records finish the order; R writes ISA where a rank changed.                                    (m)
 // Rotations still tied when depth >= n are identical: the block is periodic and
 // is flagged BZX_ST_PERIODIC (tie order fixed by bzx_periodic.hip); L is unaffected.
 //
 // HBM-bound integer work: records stream coalesced as 8-byte words; see DESIGN.md section 6 for the
-// measured traffic.
+// measured traffic per phase.
 #include <hip/hip_runtime.h>
 #include "bzx_device.h"
 #include "bzx_wg.h"
@@ -587,24 +589,13 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
                 if (TEXT) {
                     uint32_t p = ((uint32_t)(v[j].rec >> TXT_SA_SHIFT) & 0xFFFFFu) + hmod;
                     if (p >= n) p -= n;
-#ifdef BZX_EXP_NOGATHER
-                    const uint64_t w0 = (uint64_t)p * 0x9E3779B97F4A7C15ull;
-#else
                     const uint64_t w0 = text_key8(T, n, p);
-#endif
                     uint64_t w1 = 0;
                     if (csym > 8) {
                         uint32_t p2 = p + 8;
                         while (p2 >= n) p2 -= n;
-#ifdef BZX_EXP_NOGATHER
-                        w1 = (uint64_t)p2 * 0xC2B2AE3D27D4EB4Full;
-#else
                         w1 = text_key8(T, n, p2);
-#endif
                     }
-#ifdef BZX_EXP_NOPACK
-                    v[j].key = w0 ^ (w1 >> 3);
-#else
                     uint32_t sy[16];
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
@@ -616,7 +607,6 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
                     for (int q = 0; q < 16; q++)
                         if ((uint32_t)q < csym) key = (key << bits) | (uint64_t)sy[q];
                     v[j].key = key;
-#endif
                     v[j].rec &= ~(0x3FFull << TXT_KEY_SHIFT);     // clear the tile-local slot of the last round
                 } else {
                     uint32_t p = ((uint32_t)(v[j].rec >> RNK_SA_SHIFT) & 0xFFFFFu) + hmod;
@@ -628,9 +618,7 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
                 v[j].key = ~0ull;
             }
         }
-#ifndef BZX_EXP_NOSORT
         bitonic_tile<TEXT, SEG_PER_LANE>(v, lane);
-#endif
         if (TEXT) {
             // tile-local index of the first member of every new (g, key) group -> record bits 28..37
             SegRec pl;                                     // last element of the previous lane
