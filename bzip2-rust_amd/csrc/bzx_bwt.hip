@@ -16,7 +16,7 @@
 //       groups larger than a tile are split by single symbols (counting sorts inside the group's range);
 //       groups that resist are FROZEN for the RANK rounds; then each wave sorts tiles of <= 256 records,
 //       cut at group boundaries, by (g, next csym symbols at sa+depth) with a register / cross-lane
-//       bitonic network.  No ISA exists in this mode: the only random accesses are 16-byte reads of the
+//       bitonic network.  No ISA exists in this mode: the only random accesses are 8-byte reads of the
 //       block itself.                                                                                    (m)
 //   RANK rounds (only for deep repeats; h doubles): ISA is built once from SA (radix pass + LDS windows),
 //       key2 = ISA[(sa+h) mod n]; oversized groups are split by the digits of key2, wave tiles of <= 512
@@ -47,6 +47,8 @@
 #define MODE_TEXT 1
 #define MODE_RANK 2
 #define TEXT_ROUNDS 4
+// symbols per TEXT round key: one 8-byte read of the block per rotation (measured: 8 beats 6, 7, 10 and 12)
+#define CSYM_MAX 8
 // TEXT records of a group that the symbol-wise splitter gave up on (deep repeats inside a large group): the
 // group is left alone by the tile rounds and resolved by prefix doubling (RANK rounds) afterwards
 #define TXT_FROZEN (1ull << 38)
@@ -590,21 +592,12 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
                     uint32_t p = ((uint32_t)(v[j].rec >> TXT_SA_SHIFT) & 0xFFFFFu) + hmod;
                     if (p >= n) p -= n;
                     const uint64_t w0 = text_key8(T, n, p);
-                    uint64_t w1 = 0;
-                    if (csym > 8) {
-                        uint32_t p2 = p + 8;
-                        while (p2 >= n) p2 -= n;
-                        w1 = text_key8(T, n, p2);
-                    }
-                    uint32_t sy[16];
+                    uint32_t sy[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        sy[q] = s_seq[(uint32_t)(w0 >> (56 - 8 * q)) & 255u];
-                        sy[q + 8] = s_seq[(uint32_t)(w1 >> (56 - 8 * q)) & 255u];
-                    }
+                    for (int q = 0; q < 8; q++) sy[q] = s_seq[(uint32_t)(w0 >> (56 - 8 * q)) & 255u];
                     uint64_t key = 0;
 #pragma unroll
-                    for (int q = 0; q < 16; q++)
+                    for (int q = 0; q < 8; q++)
                         if ((uint32_t)q < csym) key = (key << bits) | (uint64_t)sy[q];
                     v[j].key = key;
                     v[j].rec &= ~(0x3FFull << TXT_KEY_SHIFT);     // clear the tile-local slot of the last round
@@ -947,7 +940,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         uint32_t bits = 1;
         while ((1u << bits) < n_in_use) bits++;
         const uint32_t ksym = 32 / bits < 8 ? 32 / bits : 8;          // symbols in the 32-bit initial key
-        const uint32_t csym = 64 / bits < 16 ? 64 / bits : 16;        // symbols in a 64-bit round key
+        const uint32_t csym = 64 / bits < CSYM_MAX ? 64 / bits : CSYM_MAX;        // symbols in a round key
 
         // ---- I1: four digit histograms of the INIT records (the records themselves are built by pass 1)
         for (uint32_t i = tid; i < 4 * 256; i += SORT_NT) (&s_hist[0][0])[i] = 0;
