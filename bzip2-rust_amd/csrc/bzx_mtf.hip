@@ -30,22 +30,39 @@ __shared__ uint32_t m_freq[BZX_MAX_ALPHA + 2];
 __shared__ uint32_t m_scratch[2 * (MTF_NT / 64)];
 __shared__ uint32_t m_bcast[4];   // [0] block, [1] carry last-nonzero+1, [2] carry output count
 
-struct Seen256 {
-    uint64_t w0, w1, w2, w3;
-    __device__ __forceinline__ void clear() { w0 = w1 = w2 = w3 = 0; }
+// Set of dense symbol ids < 64 * NW, one bit each, in registers (NW = 1, 2 or 4 words).
+template <int NW> struct SeenSet {
+    uint64_t w[NW];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int i = 0; i < NW; i++) w[i] = 0;
+    }
     // returns true if s was already present; marks it
     __device__ __forceinline__ bool test_set(uint32_t s)
     {
         const uint64_t bit = 1ull << (s & 63u);
-        uint64_t *w = s < 128u ? (s < 64u ? &w0 : &w1) : (s < 192u ? &w2 : &w3);
-        const bool was = (*w & bit) != 0;
-        *w |= bit;
+        if (NW == 1) {
+            const bool was = (w[0] & bit) != 0;
+            w[0] |= bit;
+            return was;
+        }
+        const uint32_t q = s >> 6;
+        bool was = false;
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const bool here = q == (uint32_t)i;
+            was = was || (here && (w[i] & bit) != 0);
+            w[i] |= here ? bit : 0ull;
+        }
         return was;
     }
     __device__ __forceinline__ bool test(uint32_t s) const
     {
-        const uint64_t w = s < 128u ? (s < 64u ? w0 : w1) : (s < 192u ? w2 : w3);
-        return (w >> (s & 63u)) & 1ull;
+        uint64_t x = w[0];
+#pragma unroll
+        for (int i = 1; i < NW; i++) x = (s >> 6) == (uint32_t)i ? w[i] : x;
+        return (x >> (s & 63u)) & 1ull;
     }
 };
 
@@ -105,6 +122,93 @@ __device__ __forceinline__ void mtf_ranks_regs(const uint8_t *__restrict__ L, ui
             }
         }
         *reinterpret_cast<uint4 *>(R + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// Recency list of chunk [c_lo, c_hi): distinct symbols by last occurrence, most recent first.
+template <int NW>
+__device__ __forceinline__ void mtf_recency(const uint8_t *__restrict__ L, uint32_t c_lo, uint32_t c_hi, uint32_t n_in_use,
+                                            uint8_t *rec, uint16_t *cnt_out)
+{
+    SeenSet<NW> seen;
+    seen.clear();
+    uint32_t cnt = 0;
+    // 16 bytes per load, walking backwards (chunk starts are 16-byte aligned, slabs 256-byte aligned)
+    uint4 nxt = *reinterpret_cast<const uint4 *>(L + ((c_hi - 1) & ~15u));
+    for (uint32_t i0 = (c_hi - 1) & ~15u; cnt < n_in_use;) {
+        const uint4 v = nxt;
+        if (i0 != c_lo) nxt = *reinterpret_cast<const uint4 *>(L + i0 - 16);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 3; q >= 0; q--) {
+#pragma unroll
+            for (int k = 3; k >= 0; k--) {
+                const uint32_t i = i0 + (uint32_t)(q * 4 + k);
+                if (i < c_hi) {
+                    const uint32_t s = m_seq[(w[q] >> (8 * k)) & 255u];
+                    if (!seen.test_set(s)) rec[cnt++] = (uint8_t)s;
+                }
+            }
+        }
+        if (i0 == c_lo) break;
+        i0 -= 16;
+    }
+    *cnt_out = (uint16_t)cnt;
+}
+
+// (a) recency list of every group of MTF_GROUP chunks (one lane per group); (b) the MTF list at my chunk start:
+// earlier chunks of my group, then earlier groups, most recent first, then the never-seen symbols in id order.
+template <int NW>
+__device__ __forceinline__ void mtf_start_lists(uint32_t tid, uint32_t nch_used, uint32_t n_in_use, uint32_t stride,
+                                                bool have_chunk)
+{
+    if (tid * MTF_GROUP < nch_used) {
+        SeenSet<NW> seen;
+        seen.clear();
+        uint32_t cnt = 0;
+        uint8_t *sup = m_super + tid * 264;
+        const uint32_t g_lo = tid * MTF_GROUP;
+        const uint32_t g_hi = g_lo + MTF_GROUP < nch_used ? g_lo + MTF_GROUP : nch_used;
+        for (uint32_t c = g_hi; c > g_lo && cnt < n_in_use;) {
+            c--;
+            const uint8_t *rec = m_rec + c * stride;
+            const uint32_t rc = m_reccnt[c];
+            for (uint32_t k = 0; k < rc; k++) {
+                const uint32_t s = rec[k];
+                if (!seen.test_set(s)) sup[cnt++] = (uint8_t)s;
+            }
+        }
+        m_supercnt[tid] = (uint16_t)cnt;
+    }
+    __syncthreads();
+    if (have_chunk) {
+        SeenSet<NW> seen;
+        seen.clear();
+        uint32_t cnt = 0;
+        uint8_t *lst = m_list + tid * stride;
+        const uint32_t g = tid / MTF_GROUP;
+        for (uint32_t c = tid; c > g * MTF_GROUP && cnt < n_in_use;) {
+            c--;
+            const uint8_t *rec = m_rec + c * stride;
+            const uint32_t rc = m_reccnt[c];
+            for (uint32_t k = 0; k < rc; k++) {
+                const uint32_t s = rec[k];
+                if (!seen.test_set(s)) lst[cnt++] = (uint8_t)s;
+            }
+        }
+        for (uint32_t gg = g; gg > 0 && cnt < n_in_use;) {
+            gg--;
+            const uint8_t *sup = m_super + gg * 264;
+            const uint32_t rc = m_supercnt[gg];
+            for (uint32_t k = 0; k < rc; k++) {
+                const uint32_t s = sup[k];
+                if (!seen.test_set(s)) lst[cnt++] = (uint8_t)s;
+            }
+        }
+        // symbols never seen so far keep the initial (ascending) order
+        for (uint32_t s = 0; s < n_in_use && cnt < n_in_use; s++)
+            if (!seen.test(s)) lst[cnt++] = (uint8_t)s;
+        for (; cnt < stride; cnt++) lst[cnt] = 0xff;           // padding never matches before a real entry
     }
 }
 
@@ -179,85 +283,17 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
 
         // ---- 3. recency list of my chunk: distinct symbols by last occurrence, most recent first
         if (have_chunk) {
-            Seen256 seen;
-            seen.clear();
-            uint32_t cnt = 0;
-            uint8_t *rec = m_rec + tid * stride;
-            // 16 bytes per load, walking backwards (chunk starts are 16-byte aligned, slabs 256-byte aligned)
-            uint4 nxt = *reinterpret_cast<const uint4 *>(L + ((c_hi - 1) & ~15u));
-            for (uint32_t i0 = (c_hi - 1) & ~15u; cnt < n_in_use;) {
-                const uint4 v = nxt;
-                if (i0 != c_lo) nxt = *reinterpret_cast<const uint4 *>(L + i0 - 16);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int q = 3; q >= 0; q--) {
-#pragma unroll
-                    for (int k = 3; k >= 0; k--) {
-                        const uint32_t i = i0 + (uint32_t)(q * 4 + k);
-                        if (i < c_hi) {
-                            const uint32_t s = m_seq[(w[q] >> (8 * k)) & 255u];
-                            if (!seen.test_set(s)) rec[cnt++] = (uint8_t)s;
-                        }
-                    }
-                }
-                if (i0 == c_lo) break;
-                i0 -= 16;
-            }
-            m_reccnt[tid] = (uint16_t)cnt;
+            if (n_in_use <= 64) mtf_recency<1>(L, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid]);
+            else if (n_in_use <= 128) mtf_recency<2>(L, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid]);
+            else mtf_recency<4>(L, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid]);
         }
         __syncthreads();
         MTF_STAMP(33);
 
-        // ---- 4a. recency list of every group of 32 chunks (one lane per group)
-        if (tid * MTF_GROUP < nch_used) {
-            Seen256 seen;
-            seen.clear();
-            uint32_t cnt = 0;
-            uint8_t *sup = m_super + tid * 264;
-            const uint32_t g_lo = tid * MTF_GROUP;
-            const uint32_t g_hi = g_lo + MTF_GROUP < nch_used ? g_lo + MTF_GROUP : nch_used;
-            for (uint32_t c = g_hi; c > g_lo && cnt < n_in_use;) {
-                c--;
-                const uint8_t *rec = m_rec + c * stride;
-                const uint32_t rc = m_reccnt[c];
-                for (uint32_t k = 0; k < rc; k++) {
-                    const uint32_t s = rec[k];
-                    if (!seen.test_set(s)) sup[cnt++] = (uint8_t)s;
-                }
-            }
-            m_supercnt[tid] = (uint16_t)cnt;
-        }
-        __syncthreads();
-        // ---- 4b. MTF list at my chunk start: earlier chunks of my group, then earlier groups, most recent first
-        if (have_chunk) {
-            Seen256 seen;
-            seen.clear();
-            uint32_t cnt = 0;
-            uint8_t *lst = m_list + tid * stride;
-            const uint32_t g = tid / MTF_GROUP;
-            for (uint32_t c = tid; c > g * MTF_GROUP && cnt < n_in_use;) {
-                c--;
-                const uint8_t *rec = m_rec + c * stride;
-                const uint32_t rc = m_reccnt[c];
-                for (uint32_t k = 0; k < rc; k++) {
-                    const uint32_t s = rec[k];
-                    if (!seen.test_set(s)) lst[cnt++] = (uint8_t)s;
-                }
-            }
-            for (uint32_t gg = g; gg > 0 && cnt < n_in_use;) {
-                gg--;
-                const uint8_t *sup = m_super + gg * 264;
-                const uint32_t rc = m_supercnt[gg];
-                for (uint32_t k = 0; k < rc; k++) {
-                    const uint32_t s = sup[k];
-                    if (!seen.test_set(s)) lst[cnt++] = (uint8_t)s;
-                }
-            }
-            // symbols never seen so far keep the initial (ascending) order
-            for (uint32_t s = 0; s < n_in_use && cnt < n_in_use; s++)
-                if (!seen.test(s)) lst[cnt++] = (uint8_t)s;
-            for (; cnt < stride; cnt++) lst[cnt] = 0xff;           // padding never matches before a real entry
-        }
+        // ---- 4. MTF list at every chunk start (two-level walk over the recency lists)
+        if (n_in_use <= 64) mtf_start_lists<1>(tid, nch_used, n_in_use, stride, have_chunk);
+        else if (n_in_use <= 128) mtf_start_lists<2>(tid, nch_used, n_in_use, stride, have_chunk);
+        else mtf_start_lists<4>(tid, nch_used, n_in_use, stride, have_chunk);
         __syncthreads();
         MTF_STAMP(34);
 
