@@ -289,7 +289,7 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         const uint32_t rem = nblk % ncu, idle = ncu - rem;
         if ((stages & STG_MTF) && per_cu == 1 && nblk > ncu && rem != 0 && idle * 8 >= ncu) {
             const uint32_t full = nblk - rem;
-            const uint32_t n_a1 = full < idle * 5 ? full : idle * 5;      // a block sorts in roughly 5 MTF times
+            const uint32_t n_a1 = full < idle * 6 ? full : idle * 6;      // a block sorts in roughly 6 MTF times
             BzxBatch Ba = B;
             Ba.nblk = full;
             bzx_launch_bwt(Ba, ncu, ctx->stream);

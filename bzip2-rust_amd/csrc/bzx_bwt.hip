@@ -928,7 +928,19 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         // ---- A: bytes in use -> dense symbol ids; symbols per key
         if (tid < 256) s_inuse[tid] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += SORT_NT) s_inuse[T[i]] = 1;
+        {
+            const uint32_t n16 = n & ~15u;
+            for (uint32_t i = tid * 16; i < n16; i += SORT_NT * 16) {
+                uint4 v;
+                __builtin_memcpy(&v, T + i, 16);          // unaligned: zero-copy blocks start anywhere in the raw input
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) s_inuse[(w[q] >> (8 * k)) & 255u] = 1;
+            }
+            for (uint32_t i = n16 + tid; i < n; i += SORT_NT) s_inuse[T[i]] = 1;
+        }
         __syncthreads();
         uint32_t n_in_use;
         {
@@ -945,14 +957,22 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         // ---- I1: four digit histograms of the INIT records (the records themselves are built by pass 1)
         for (uint32_t i = tid; i < 4 * 256; i += SORT_NT) (&s_hist[0][0])[i] = 0;
         __syncthreads();
-        for (uint32_t t0 = 0; t0 < n; t0 += SORT_NT) {
-            const uint32_t i = t0 + tid;
-            const bool valid = i < n;
-            const uint32_t key = valid ? pack_symbols32(text_key8(T, n, i), bits, ksym) : 0u;
-            // packed symbol keys spread over the digits: plain LDS atomics (no wave aggregation needed)
-            if (valid) {
+        for (uint32_t t0 = 0; t0 < n; t0 += SORT_NT * SORT_E) {
+            uint64_t w[SORT_E];                       // all loads of the step in flight before the first use
 #pragma unroll
-                for (int p = 0; p < 4; p++) atomicAdd(&s_hist[p][(key >> (8 * p)) & 255u], 1u);
+            for (int e = 0; e < SORT_E; e++) {
+                const uint32_t i = t0 + e * SORT_NT + tid;
+                w[e] = i < n ? text_key8(T, n, i) : 0ull;
+            }
+#pragma unroll
+            for (int e = 0; e < SORT_E; e++) {
+                const uint32_t i = t0 + e * SORT_NT + tid;
+                if (i < n) {
+                    const uint32_t key = pack_symbols32(w[e], bits, ksym);
+                    // packed symbol keys spread over the digits: plain LDS atomics (no wave aggregation needed)
+#pragma unroll
+                    for (int p = 0; p < 4; p++) atomicAdd(&s_hist[p][(key >> (8 * p)) & 255u], 1u);
+                }
             }
         }
         __syncthreads();
