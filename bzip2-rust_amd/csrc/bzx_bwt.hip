@@ -138,6 +138,47 @@ __device__ __forceinline__ uint64_t init_record(const uint8_t *__restrict__ T, u
     return ((uint64_t)key << TXT_KEY_SHIFT) | ((uint64_t)i << TXT_SA_SHIFT) | (uint64_t)prev;
 }
 
+// INIT records (or just the keys) of the SORT_E consecutive rotations i0 .. i0+3: their 8-byte windows overlap,
+// so 11 symbol lookups serve four keys instead of 32.  nvalid = how many of the four exist (i0 + e < n).
+template <bool RECORDS>
+__device__ __forceinline__ void init_batch4(const uint8_t *__restrict__ T, uint32_t n, uint32_t i0, uint32_t nvalid,
+                                            uint32_t bits, uint32_t ksym, uint64_t (&out)[SORT_E])
+{
+#pragma unroll
+    for (int e = 0; e < SORT_E; e++) out[e] = 0;
+    if (nvalid == 0) return;
+    const uint64_t wa = text_key8(T, n, i0);                  // bytes i0 .. i0+7 (cyclic)
+    uint32_t pb = i0 + 4;
+    while (pb >= n) pb -= n;
+    const uint64_t wb = text_key8(T, n, pb);                  // bytes i0+4 .. i0+11
+    uint32_t id[11];
+#pragma unroll
+    for (int j = 0; j < 8; j++) id[j] = s_seq[(uint32_t)(wa >> (56 - 8 * j)) & 255u];
+#pragma unroll
+    for (int j = 8; j < 11; j++) id[j] = s_seq[(uint32_t)(wb >> (56 - 8 * (j - 4))) & 255u];
+    const uint32_t spare = 32u - ksym * bits;
+    const uint32_t prev0 = RECORDS ? T[i0 ? i0 - 1 : n - 1] : 0u;
+#pragma unroll
+    for (int e = 0; e < SORT_E; e++) {
+        uint32_t key = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if ((uint32_t)j < ksym) key = (key << bits) | id[e + j];
+        uint32_t nx = 0;                                      // id[e + ksym] without a dynamically indexed array
+#pragma unroll
+        for (int j = 4; j < 8; j++) nx = ksym == (uint32_t)j ? id[e + j] : nx;
+        if (ksym < 8 && spare) key = (key << spare) | (nx >> (bits - spare));
+        if ((uint32_t)e < nvalid) {
+            if (RECORDS) {
+                const uint32_t prev = e == 0 ? prev0 : (uint32_t)(wa >> (56 - 8 * (e - 1))) & 255u;
+                out[e] = ((uint64_t)key << TXT_KEY_SHIFT) | ((uint64_t)(i0 + e) << TXT_SA_SHIFT) | (uint64_t)prev;
+            } else {
+                out[e] = key;
+            }
+        }
+    }
+}
+
 // One stable LSD pass: src[0..m) -> dst by the 8-bit digit at `shift`; hist = digit histogram (LDS).
 // SRC_TEXT: the source records are generated on the fly from the block bytes (first pass of the initial sort).
 // SRC_SA:   the source records are [SA[j]:20 @20 | j:20 @0] generated from the suffix array (ISA build).
@@ -151,6 +192,13 @@ __device__ __forceinline__ uint64_t radix_source(const uint64_t *__restrict__ sr
     if (SRC == SRC_TEXT) return init_record(T, m, idx, bits, ksym);
     if (SRC == SRC_SA) return ((uint64_t)((const uint32_t *)T)[idx] << 20) | (uint64_t)idx;
     return src[idx];
+}
+
+// record index of slot e of a lane: SRC_TEXT gives every lane SORT_E consecutive rotations (init_batch4); the order in
+// which a pass visits equal digits only permutes rotations that tie on the whole key, which is irrelevant
+template <int SRC> __device__ __forceinline__ uint32_t radix_index(uint32_t wbase, int e, uint32_t lane)
+{
+    return SRC == SRC_TEXT ? wbase + lane * SORT_E + (uint32_t)e : wbase + (uint32_t)e * 64 + lane;
 }
 
 template <int SRC>
@@ -176,10 +224,15 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
     uint64_t nxt[SORT_E];
     {
         const uint32_t wbase = wave * (64 * SORT_E);
+        if (SRC == SRC_TEXT) {
+            const uint32_t i0 = wbase + lane * SORT_E;
+            init_batch4<true>(T, m, i0 < m ? i0 : 0u, i0 >= m ? 0u : (m - i0 < SORT_E ? m - i0 : (uint32_t)SORT_E), bits, ksym, nxt);
+        } else {
 #pragma unroll
-        for (int e = 0; e < SORT_E; e++) {
-            const uint32_t idx = wbase + e * 64 + lane;
-            nxt[e] = idx < m ? radix_source<SRC>(src, idx, m, T, bits, ksym) : 0ull;
+            for (int e = 0; e < SORT_E; e++) {
+                const uint32_t idx = wbase + e * 64 + lane;
+                nxt[e] = idx < m ? radix_source<SRC>(src, idx, m, T, bits, ksym) : 0ull;
+            }
         }
     }
     for (uint32_t t0 = 0; t0 < m; t0 += SORT_NT * SORT_E) {
@@ -190,10 +243,15 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
         for (int e = 0; e < SORT_E; e++) rec[e] = nxt[e];
         {
             const uint32_t nbase = wbase + SORT_NT * SORT_E;
+            if (SRC == SRC_TEXT) {
+                const uint32_t i0 = nbase + lane * SORT_E;
+                init_batch4<true>(T, m, i0 < m ? i0 : 0u, i0 >= m ? 0u : (m - i0 < SORT_E ? m - i0 : (uint32_t)SORT_E), bits, ksym, nxt);
+            } else {
 #pragma unroll
-            for (int e = 0; e < SORT_E; e++) {
-                const uint32_t idx = nbase + e * 64 + lane;
-                nxt[e] = idx < m ? radix_source<SRC>(src, idx, m, T, bits, ksym) : 0ull;
+                for (int e = 0; e < SORT_E; e++) {
+                    const uint32_t idx = nbase + e * 64 + lane;
+                    nxt[e] = idx < m ? radix_source<SRC>(src, idx, m, T, bits, ksym) : 0ull;
+                }
             }
         }
         uint32_t *wc = &s_wcnt[cur][wave * 256];
@@ -202,7 +260,7 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
 #endif
 #pragma unroll
         for (int e = 0; e < SORT_E; e++) {
-            const uint32_t idx = wbase + e * 64 + lane;
+            const uint32_t idx = radix_index<SRC>(wbase, e, lane);
             const bool valid = idx < m;
             const uint32_t d = (uint32_t)(rec[e] >> shift) & 255u;
 #if RADIX_LDS_MATCH
@@ -255,7 +313,7 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
         const uint32_t wp1 = s_wpart[0], wp2 = wp1 + s_wpart[1], wp3 = wp2 + s_wpart[2];
 #pragma unroll
         for (int e = 0; e < SORT_E; e++) {
-            const uint32_t idx = wbase + e * 64 + lane;
+            const uint32_t idx = radix_index<SRC>(wbase, e, lane);
             if (idx < m) {
                 const uint32_t d = dig[e], q = d >> 6;
                 const uint32_t lb = s_lbase[d] + (q == 0 ? 0u : q == 1 ? wp1 : q == 2 ? wp2 : wp3);
@@ -291,7 +349,7 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
         bzx_lds_barrier();
 #pragma unroll
         for (int e = 0; e < SORT_E; e++) {
-            const uint32_t idx = wbase + e * 64 + lane;
+            const uint32_t idx = radix_index<SRC>(wbase, e, lane);
             if (idx < m) dst[wc[dig[e]] + off[e]] = rec[e];
         }
 #endif
@@ -958,17 +1016,14 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         for (uint32_t i = tid; i < 4 * 256; i += SORT_NT) (&s_hist[0][0])[i] = 0;
         __syncthreads();
         for (uint32_t t0 = 0; t0 < n; t0 += SORT_NT * SORT_E) {
-            uint64_t w[SORT_E];                       // all loads of the step in flight before the first use
+            const uint32_t i0 = t0 + tid * SORT_E;          // SORT_E consecutive rotations per lane
+            const uint32_t nv = i0 >= n ? 0u : (n - i0 < SORT_E ? n - i0 : (uint32_t)SORT_E);
+            uint64_t keys[SORT_E];
+            init_batch4<false>(T, n, nv ? i0 : 0u, nv, bits, ksym, keys);
 #pragma unroll
             for (int e = 0; e < SORT_E; e++) {
-                const uint32_t i = t0 + e * SORT_NT + tid;
-                w[e] = i < n ? text_key8(T, n, i) : 0ull;
-            }
-#pragma unroll
-            for (int e = 0; e < SORT_E; e++) {
-                const uint32_t i = t0 + e * SORT_NT + tid;
-                if (i < n) {
-                    const uint32_t key = pack_symbols32(w[e], bits, ksym);
+                if ((uint32_t)e < nv) {
+                    const uint32_t key = (uint32_t)keys[e];
                     // packed symbol keys spread over the digits: plain LDS atomics (no wave aggregation needed)
 #pragma unroll
                     for (int p = 0; p < 4; p++) atomicAdd(&s_hist[p][(key >> (8 * p)) & 255u], 1u);
