@@ -47,8 +47,6 @@
 #define MODE_TEXT 1
 #define MODE_RANK 2
 #define TEXT_ROUNDS 4
-// symbols per TEXT round key: one 8-byte read of the block per rotation (measured: 8 beats 6, 7, 10 and 12)
-#define CSYM_MAX 8
 // TEXT records of a group that the symbol-wise splitter gave up on (deep repeats inside a large group): the
 // group is left alone by the tile rounds and resolved by prefix doubling (RANK rounds) afterwards
 #define TXT_FROZEN (1ull << 38)
@@ -92,91 +90,83 @@ __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t d, bool valid)
     }
 }
 
-// 8 block bytes starting at cyclic position p (p < n), big-endian
-__device__ __forceinline__ uint64_t text_key8(const uint8_t *__restrict__ T, uint32_t n, uint32_t p)
+// ---- the packed block --------------------------------------------------------------------------------------
+// Alphabet packing: the block's bytes are mapped to dense, order-preserving ids (s_seq) of `bits` bits each and
+// written once, most significant bit first, as one bit string P (symbol i at bit i*bits), continued cyclically
+// for PK_PAD symbols past the end.  Every key the sort needs is then ONE unaligned 8-byte read of P and a shift:
+// the 32-bit initial key is the first 32 bits of rotation i (32/bits whole symbols and the top of the next one:
+// fixed-width ids keep integer order == lexicographic order), a round key is the next csym symbols.
+#define PK_PAD 80u            // symbols of cyclic continuation: a 64-bit window at the last symbol stays inside P
+#define PK_OFFSET 65536u      // P lives in the ISA array (unused in TEXT mode) behind the splitter's scratch lists
+
+// >= 57 valid bits of rotation pos, most significant first
+__device__ __forceinline__ uint64_t pk_window(const uint8_t *__restrict__ P, uint32_t pos, uint32_t bits)
 {
-    if (p + 8 <= n) {
-        uint64_t w;
-        __builtin_memcpy(&w, T + p, 8);      // unaligned 8-byte global load
-        return __builtin_bswap64(w);
-    }
-    uint64_t w = 0;
-    for (int j = 0; j < 8; j++) {
-        w = (w << 8) | T[p];
-        p++;
-        if (p >= n) p = 0;
-    }
-    return w;
+    const uint32_t b = pos * bits;
+    uint64_t w;
+    __builtin_memcpy(&w, P + (b >> 3), 8);      // unaligned 8-byte global load
+    return __builtin_bswap64(w) << (b & 7u);
 }
 
-
-// Alphabet packing: the block's bytes are mapped to dense ids (s_seq) of `bits` bits each, so a 32-bit
-// initial key holds ksym = min(8, 32/bits) symbols (6 for ordinary text) instead of 4 bytes, and a 64-bit
-// round key holds up to 16.  Fixed-width ids keep integer order == lexicographic order.
-__device__ __forceinline__ uint32_t pack_symbols32(uint64_t w, uint32_t bits, uint32_t ksym)
+// Builds P from the block: one lane per 64 symbols = `bits` whole 8-byte words (big-endian bit order).
+__device__ __attribute__((noinline)) void pk_build(const uint8_t *__restrict__ T, uint32_t n, uint32_t bits,
+                                                   uint8_t *__restrict__ P)
 {
-    uint32_t sy[8];
+    const uint32_t ngroups = (n + PK_PAD + 63u) / 64u + 1u;       // one group of zeros behind the continuation
+    for (uint32_t q = threadIdx.x; q < ngroups; q += SORT_NT) {
+        const uint32_t pos = 64u * q;
+        uint32_t c[16];                                            // 64 block bytes, cyclic
+        if (pos + 64u <= n) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) sy[j] = s_seq[(uint32_t)(w >> (56 - 8 * j)) & 255u];   // independent LDS reads
-    uint32_t key = 0;
+            for (int k = 0; k < 4; k++) {
+                uint4 v;
+                __builtin_memcpy(&v, T + pos + 16 * k, 16);
+                c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
+            }
+        } else {
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-        if ((uint32_t)j < ksym) key = (key << bits) | sy[j];
-    // the bits left over (4 of 32 for a 7-bit alphabet) hold the top bits of the next symbol: still order
-    // preserving, and groups that tie on the key still agree on ksym whole symbols
-    const uint32_t spare = 32u - ksym * bits;
-    if (ksym < 8 && spare) key = (key << spare) | (sy[ksym] >> (bits - spare));
-    return key;
-}
-
-// INIT record of rotation i: [first ksym symbols:32 @28 | i:20 @8 | preceding byte:8 @0]
-__device__ __forceinline__ uint64_t init_record(const uint8_t *__restrict__ T, uint32_t n, uint32_t i, uint32_t bits,
-                                                uint32_t ksym)
-{
-    const uint32_t key = pack_symbols32(text_key8(T, n, i), bits, ksym);
-    const uint32_t prev = T[i ? i - 1 : n - 1];
-    return ((uint64_t)key << TXT_KEY_SHIFT) | ((uint64_t)i << TXT_SA_SHIFT) | (uint64_t)prev;
-}
-
-// INIT records (or just the keys) of the SORT_E consecutive rotations i0 .. i0+3: their 8-byte windows overlap,
-// so 11 symbol lookups serve four keys instead of 32.  nvalid = how many of the four exist (i0 + e < n).
-template <bool RECORDS>
-__device__ __forceinline__ void init_batch4(const uint8_t *__restrict__ T, uint32_t n, uint32_t i0, uint32_t nvalid,
-                                            uint32_t bits, uint32_t ksym, uint64_t (&out)[SORT_E])
-{
+            for (int k = 0; k < 16; k++) c[k] = 0;
+            if (pos < n + PK_PAD) {
+                uint32_t pm = pos % n;
+                for (int j = 0; j < 64; j++) {
+                    c[j >> 2] |= (uint32_t)T[pm] << (8 * (j & 3));
+                    pm = pm + 1 == n ? 0u : pm + 1;
+                }
+            }
+        }
+        uint64_t *out = reinterpret_cast<uint64_t *>(P) + (size_t)q * bits;      // P is 8-byte aligned
+        uint64_t acc = 0;
+        uint32_t have = 0;                                         // bits in acc
+        const bool real = pos < n + PK_PAD;
 #pragma unroll
-    for (int e = 0; e < SORT_E; e++) out[e] = 0;
-    if (nvalid == 0) return;
-    const uint64_t wa = text_key8(T, n, i0);                  // bytes i0 .. i0+7 (cyclic)
-    uint32_t pb = i0 + 4;
-    while (pb >= n) pb -= n;
-    const uint64_t wb = text_key8(T, n, pb);                  // bytes i0+4 .. i0+11
-    uint32_t id[11];
-#pragma unroll
-    for (int j = 0; j < 8; j++) id[j] = s_seq[(uint32_t)(wa >> (56 - 8 * j)) & 255u];
-#pragma unroll
-    for (int j = 8; j < 11; j++) id[j] = s_seq[(uint32_t)(wb >> (56 - 8 * (j - 4))) & 255u];
-    const uint32_t spare = 32u - ksym * bits;
-    const uint32_t prev0 = RECORDS ? T[i0 ? i0 - 1 : n - 1] : 0u;
-#pragma unroll
-    for (int e = 0; e < SORT_E; e++) {
-        uint32_t key = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if ((uint32_t)j < ksym) key = (key << bits) | id[e + j];
-        uint32_t nx = 0;                                      // id[e + ksym] without a dynamically indexed array
-#pragma unroll
-        for (int j = 4; j < 8; j++) nx = ksym == (uint32_t)j ? id[e + j] : nx;
-        if (ksym < 8 && spare) key = (key << spare) | (nx >> (bits - spare));
-        if ((uint32_t)e < nvalid) {
-            if (RECORDS) {
-                const uint32_t prev = e == 0 ? prev0 : (uint32_t)(wa >> (56 - 8 * (e - 1))) & 255u;
-                out[e] = ((uint64_t)key << TXT_KEY_SHIFT) | ((uint64_t)(i0 + e) << TXT_SA_SHIFT) | (uint64_t)prev;
-            } else {
-                out[e] = key;
+        for (int j = 0; j < 64; j++) {
+            const uint64_t id = real ? s_seq[(c[j >> 2] >> (8 * (j & 3))) & 255u] : 0u;
+            if (have + bits <= 64u) {
+                acc = bits == 64u ? id : (acc << bits) | id;
+                have += bits;
+            } else {                                               // the symbol straddles a word boundary
+                const uint32_t hi = 64u - have, lo = bits - hi;
+                *out++ = __builtin_bswap64((acc << hi) | (id >> lo));
+                acc = id & ((1ull << lo) - 1ull);
+                have = lo;
+            }
+            if (have == 64u) {
+                *out++ = __builtin_bswap64(acc);
+                acc = 0;
+                have = 0;
             }
         }
     }
+    __syncthreads();
+}
+
+// INIT record of rotation i: [first 32 bits of the packed rotation @28 | i:20 @8 | preceding byte:8 @0]
+__device__ __forceinline__ uint64_t init_record(const uint8_t *__restrict__ T, const uint8_t *__restrict__ P, uint32_t n,
+                                                uint32_t i, uint32_t bits)
+{
+    const uint32_t key = (uint32_t)(pk_window(P, i, bits) >> 32);
+    const uint32_t prev = T[i ? i - 1 : n - 1];
+    return ((uint64_t)key << TXT_KEY_SHIFT) | ((uint64_t)i << TXT_SA_SHIFT) | (uint64_t)prev;
 }
 
 // One stable LSD pass: src[0..m) -> dst by the 8-bit digit at `shift`; hist = digit histogram (LDS).
@@ -185,26 +175,56 @@ __device__ __forceinline__ void init_batch4(const uint8_t *__restrict__ T, uint3
 #define SRC_REC 0
 #define SRC_TEXT 1
 #define SRC_SA 2
-template <int SRC>
-__device__ __forceinline__ uint64_t radix_source(const uint64_t *__restrict__ src, uint32_t idx, uint32_t m,
-                                                 const uint8_t *__restrict__ T, uint32_t bits, uint32_t ksym)
+// Keys of the SORT_E = 4 consecutive rotations i0 .. i0+3 from ONE window of P: rotation i0+e starts e*bits further
+// on, and 3*8 + 32 bits still lie inside the >= 57 valid bits of the window.
+__device__ __forceinline__ void init_keys4(const uint8_t *__restrict__ P, uint32_t i0, uint32_t bits, uint32_t (&key)[SORT_E])
 {
-    if (SRC == SRC_TEXT) return init_record(T, m, idx, bits, ksym);
-    if (SRC == SRC_SA) return ((uint64_t)((const uint32_t *)T)[idx] << 20) | (uint64_t)idx;
-    return src[idx];
+    const uint64_t x = pk_window(P, i0, bits);
+#pragma unroll
+    for (int e = 0; e < SORT_E; e++) key[e] = (uint32_t)((x << ((uint32_t)e * bits)) >> 32);
 }
 
-// record index of slot e of a lane: SRC_TEXT gives every lane SORT_E consecutive rotations (init_batch4); the order in
-// which a pass visits equal digits only permutes rotations that tie on the whole key, which is irrelevant
+// INIT records of rotations i0 .. i0+3 (nvalid of them exist): one window of P, one 4-byte read of the block
+__device__ __forceinline__ void init_records4(const uint8_t *__restrict__ T, const uint8_t *__restrict__ P, uint32_t n,
+                                              uint32_t i0, uint32_t nvalid, uint32_t bits, uint64_t (&out)[SORT_E])
+{
+#pragma unroll
+    for (int e = 0; e < SORT_E; e++) out[e] = 0;
+    if (nvalid == 0) return;
+    uint32_t key[SORT_E];
+    init_keys4(P, i0, bits, key);
+    uint32_t pv = 0;                                    // bytes i0-1 .. i0+2 of the block (the preceding bytes)
+    if (i0 >= 1 && i0 + 3 <= n) {
+        __builtin_memcpy(&pv, T + i0 - 1, 4);
+    } else {
+        for (uint32_t e = 0; e < nvalid; e++) pv |= (uint32_t)T[i0 + e ? i0 + e - 1 : n - 1] << (8 * e);
+    }
+#pragma unroll
+    for (int e = 0; e < SORT_E; e++)
+        if ((uint32_t)e < nvalid)
+            out[e] = ((uint64_t)key[e] << TXT_KEY_SHIFT) | ((uint64_t)(i0 + e) << TXT_SA_SHIFT) | (uint64_t)((pv >> (8 * e)) & 255u);
+}
+
+// record index of slot e of a lane: SRC_TEXT gives every lane SORT_E consecutive rotations (init_records4); the
+// order in which a pass visits equal digits only permutes rotations that tie on the whole key, which is irrelevant
 template <int SRC> __device__ __forceinline__ uint32_t radix_index(uint32_t wbase, int e, uint32_t lane)
 {
     return SRC == SRC_TEXT ? wbase + lane * SORT_E + (uint32_t)e : wbase + (uint32_t)e * 64 + lane;
 }
 
 template <int SRC>
+__device__ __forceinline__ uint64_t radix_source(const uint64_t *__restrict__ src, uint32_t idx, uint32_t m,
+                                                 const uint8_t *__restrict__ T, uint32_t bits, const uint8_t *__restrict__ P)
+{
+    if (SRC == SRC_TEXT) return init_record(T, P, m, idx, bits);
+    if (SRC == SRC_SA) return ((uint64_t)((const uint32_t *)T)[idx] << 20) | (uint64_t)idx;
+    return src[idx];
+}
+
+template <int SRC>
 __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint32_t m, int shift,
                            const uint32_t *hist, const uint8_t *__restrict__ T = nullptr, uint32_t bits = 8,
-                           uint32_t ksym = 4)
+                           const uint8_t *__restrict__ P = nullptr)
 {
     const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
     uint32_t tot;
@@ -226,12 +246,12 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
         const uint32_t wbase = wave * (64 * SORT_E);
         if (SRC == SRC_TEXT) {
             const uint32_t i0 = wbase + lane * SORT_E;
-            init_batch4<true>(T, m, i0 < m ? i0 : 0u, i0 >= m ? 0u : (m - i0 < SORT_E ? m - i0 : (uint32_t)SORT_E), bits, ksym, nxt);
+            init_records4(T, P, m, i0 < m ? i0 : 0u, i0 >= m ? 0u : (m - i0 < SORT_E ? m - i0 : (uint32_t)SORT_E), bits, nxt);
         } else {
 #pragma unroll
             for (int e = 0; e < SORT_E; e++) {
                 const uint32_t idx = wbase + e * 64 + lane;
-                nxt[e] = idx < m ? radix_source<SRC>(src, idx, m, T, bits, ksym) : 0ull;
+                nxt[e] = idx < m ? radix_source<SRC>(src, idx, m, T, bits, P) : 0ull;
             }
         }
     }
@@ -245,12 +265,12 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
             const uint32_t nbase = wbase + SORT_NT * SORT_E;
             if (SRC == SRC_TEXT) {
                 const uint32_t i0 = nbase + lane * SORT_E;
-                init_batch4<true>(T, m, i0 < m ? i0 : 0u, i0 >= m ? 0u : (m - i0 < SORT_E ? m - i0 : (uint32_t)SORT_E), bits, ksym, nxt);
+                init_records4(T, P, m, i0 < m ? i0 : 0u, i0 >= m ? 0u : (m - i0 < SORT_E ? m - i0 : (uint32_t)SORT_E), bits, nxt);
             } else {
 #pragma unroll
                 for (int e = 0; e < SORT_E; e++) {
                     const uint32_t idx = nbase + e * 64 + lane;
-                    nxt[e] = idx < m ? radix_source<SRC>(src, idx, m, T, bits, ksym) : 0ull;
+                    nxt[e] = idx < m ? radix_source<SRC>(src, idx, m, T, bits, P) : 0ull;
                 }
             }
         }
@@ -576,7 +596,7 @@ __device__ __forceinline__ uint32_t seg_align(const uint64_t *__restrict__ U, ui
     return best;
 }
 
-// TEXT: key = block bytes [sa+h, sa+h+8) ; RANK: key2 = ISA[(sa+h) mod n] merged into the record.
+// TEXT: T = packed block, key = its next csym symbols at sa+h ; RANK: key2 = ISA[(sa+h) mod n] merged into the record.
 template <bool TEXT, int SEG_PER_LANE>
 __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ U, uint32_t m, const uint32_t *__restrict__ ISA,
                                const uint8_t *__restrict__ T, uint32_t n, uint32_t h, uint32_t bits = 8,
@@ -649,14 +669,8 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
                 if (TEXT) {
                     uint32_t p = ((uint32_t)(v[j].rec >> TXT_SA_SHIFT) & 0xFFFFFu) + hmod;
                     if (p >= n) p -= n;
-                    const uint64_t w0 = text_key8(T, n, p);
-                    uint32_t sy[8];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) sy[q] = s_seq[(uint32_t)(w0 >> (56 - 8 * q)) & 255u];
-                    uint64_t key = 0;
-#pragma unroll
-                    for (int q = 0; q < 8; q++)
-                        if ((uint32_t)q < csym) key = (key << bits) | (uint64_t)sy[q];
+                    // next csym symbols of the rotation: one 8-byte read of the packed block
+                    const uint64_t key = pk_window(T, p, bits) >> (64u - csym * bits);
                     v[j].key = key;
                     v[j].rec &= ~(0x3FFull << TXT_KEY_SHIFT);     // clear the tile-local slot of the last round
                 } else {
@@ -765,14 +779,14 @@ __device__ __forceinline__ uint32_t big_digit(uint64_t &rec, const uint8_t *__re
     if (TEXT || FETCH) {
         uint32_t p = ((uint32_t)(rec >> (TEXT ? TXT_SA_SHIFT : RNK_SA_SHIFT)) & 0xFFFFFu) + dmod;
         if (p >= n) p -= n;
-        if (TEXT) return s_seq[T[p]];
+        if (TEXT) return (uint32_t)(pk_window(T, p, pass) >> (64u - pass));      // TEXT: T = packed block, pass = bits per symbol
         rec |= (uint64_t)ISA[p] << RNK_KEY_SHIFT;
     }
     const uint32_t r = (uint32_t)(rec >> RNK_KEY_SHIFT) & 0xFFFFFu;
     return pass == 0 ? (r >> 12) & 255u : pass == 1 ? (r >> 4) & 255u : r & 15u;
 }
 
-// d: TEXT symbol index / RANK distance h.  pass: RANK digit selector.
+// d: TEXT symbol index / RANK distance h.  pass: TEXT bits per symbol / RANK digit selector.  T: TEXT packed block.
 template <bool TEXT>
 __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ U, uint64_t *__restrict__ Utmp,
                                                           const uint32_t *__restrict__ list, uint32_t nlist,
@@ -907,7 +921,8 @@ template <bool TEXT>
 __device__ __attribute__((noinline)) uint32_t big_split(uint64_t *__restrict__ U, uint64_t *__restrict__ Utmp,
                                                          const uint32_t *__restrict__ S, uint32_t m,
                                                          uint32_t *__restrict__ scratch, const uint8_t *__restrict__ T,
-                                                         const uint32_t *__restrict__ ISA, uint32_t n, uint32_t d)
+                                                         const uint32_t *__restrict__ ISA, uint32_t n, uint32_t d,
+                                                         uint32_t bits = 8)
 {
     constexpr uint32_t BIG = TEXT ? SEG_T_TEXT : SEG_T;
     constexpr uint64_t FROZEN = TEXT ? TXT_FROZEN : RNK_FROZEN;
@@ -921,7 +936,7 @@ __device__ __attribute__((noinline)) uint32_t big_split(uint64_t *__restrict__ U
         if (nlist == 0 && !ovf) return 0;
         work += before;
         if (TEXT ? (ovf || pass >= BIG_PASSES || stall >= 2 || work > 4ull * n) : (ovf || pass >= 3)) break;
-        big_split_pass<TEXT>(U, Utmp, la, nlist, lb, T, ISA, n, TEXT ? d + pass : d, pass);
+        big_split_pass<TEXT>(U, Utmp, la, nlist, lb, T, ISA, n, TEXT ? d + pass : d, TEXT ? bits : pass);
         const uint32_t after = s_big[4];
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1009,24 +1024,26 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         __syncthreads();
         uint32_t bits = 1;
         while ((1u << bits) < n_in_use) bits++;
-        const uint32_t ksym = 32 / bits < 8 ? 32 / bits : 8;          // symbols in the 32-bit initial key
-        const uint32_t csym = 64 / bits < CSYM_MAX ? 64 / bits : CSYM_MAX;        // symbols in a round key
+        const uint32_t ksym = 32 / bits;                              // whole symbols in the 32-bit initial key
+        const uint32_t csym = bits == 8 ? 8u : 56u / bits;            // symbols in a round key (one 64-bit window of P)
+        uint8_t *__restrict__ P = reinterpret_cast<uint8_t *>(ws.isa) + PK_OFFSET;
+        pk_build(T, n, bits, P);
 
         // ---- I1: four digit histograms of the INIT records (the records themselves are built by pass 1)
         for (uint32_t i = tid; i < 4 * 256; i += SORT_NT) (&s_hist[0][0])[i] = 0;
         __syncthreads();
         for (uint32_t t0 = 0; t0 < n; t0 += SORT_NT * SORT_E) {
-            const uint32_t i0 = t0 + tid * SORT_E;          // SORT_E consecutive rotations per lane
-            const uint32_t nv = i0 >= n ? 0u : (n - i0 < SORT_E ? n - i0 : (uint32_t)SORT_E);
-            uint64_t keys[SORT_E];
-            init_batch4<false>(T, n, nv ? i0 : 0u, nv, bits, ksym, keys);
+            const uint32_t i0 = t0 + tid * SORT_E;          // SORT_E consecutive rotations per lane, one window of P
+            if (i0 < n) {
+                uint32_t key[SORT_E];
+                init_keys4(P, i0, bits, key);
 #pragma unroll
-            for (int e = 0; e < SORT_E; e++) {
-                if ((uint32_t)e < nv) {
-                    const uint32_t key = (uint32_t)keys[e];
-                    // packed symbol keys spread over the digits: plain LDS atomics (no wave aggregation needed)
+                for (int e = 0; e < SORT_E; e++) {
+                    if (i0 + e < n) {
+                        // packed symbol keys spread over the digits: plain LDS atomics (no wave aggregation needed)
 #pragma unroll
-                    for (int p = 0; p < 4; p++) atomicAdd(&s_hist[p][(key >> (8 * p)) & 255u], 1u);
+                        for (int p = 0; p < 4; p++) atomicAdd(&s_hist[p][(key[e] >> (8 * p)) & 255u], 1u);
+                    }
                 }
             }
         }
@@ -1035,7 +1052,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         if (B.dbg_stop == 1) continue;
 
         // ---- I2: four LSD passes over the 32-bit key (record bits 28..59)
-        radix_pass<SRC_TEXT>(nullptr, ws.u0, n, TXT_KEY_SHIFT, s_hist[0], T, bits, ksym);
+        radix_pass<SRC_TEXT>(nullptr, ws.u0, n, TXT_KEY_SHIFT, s_hist[0], T, bits, P);
         radix_pass<SRC_REC>(ws.u0, ws.u1, n, TXT_KEY_SHIFT + 8, s_hist[1]);
         radix_pass<SRC_REC>(ws.u1, ws.u0, n, TXT_KEY_SHIFT + 16, s_hist[2]);
         radix_pass<SRC_REC>(ws.u0, ws.u1, n, TXT_KEY_SHIFT + 24, s_hist[3]);
@@ -1056,12 +1073,12 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
             const uint32_t maxgrp = s_bcast[3];
             __syncthreads();
             if (maxgrp > SEG_T_TEXT) {
-                const uint32_t fr = big_split<true>(ua, ub, sa_cur, m, ws.isa, T, nullptr, n, depth);
+                const uint32_t fr = big_split<true>(ua, ub, sa_cur, m, ws.isa, P, nullptr, n, depth, bits);
                 PHASE_STAMP(10 + (round < 7 ? round : 7) * 3);
                 if (fr && fr < frozen_depth) frozen_depth = fr;           // frozen groups agree on >= fr symbols
             }
             if (B.dbg_stop == 4) break;
-            seg_sort_round<true, 4>(ua, m, nullptr, T, n, depth, bits, csym);
+            seg_sort_round<true, 4>(ua, m, nullptr, P, n, depth, bits, csym);
             PHASE_STAMP(8 + (round < 7 ? round : 7) * 3);
             if (B.dbg_stop == 5) break;
             const uint32_t m_before = m;
