@@ -1029,23 +1029,35 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         uint8_t *__restrict__ P = reinterpret_cast<uint8_t *>(ws.isa) + PK_OFFSET;
         pk_build(T, n, bits, P);
 
-        // ---- I1: four digit histograms of the INIT records (the records themselves are built by pass 1)
-        for (uint32_t i = tid; i < 4 * 256; i += SORT_NT) (&s_hist[0][0])[i] = 0;
+        // ---- I1: four digit histograms of the INIT records (the records themselves are built by pass 1).
+        // Eight copies of the histograms (chosen by lane) keep lanes with the same digit -- common in the top
+        // digits of text -- from serialising on one LDS word; they are summed afterwards.
+        uint32_t *sub = &s_wcnt[0][0];                   // [8][4][256], free until the first pass starts
+        for (uint32_t i = tid; i < 8 * 4 * 256; i += SORT_NT) sub[i] = 0;
         __syncthreads();
-        for (uint32_t t0 = 0; t0 < n; t0 += SORT_NT * SORT_E) {
-            const uint32_t i0 = t0 + tid * SORT_E;          // SORT_E consecutive rotations per lane, one window of P
-            if (i0 < n) {
-                uint32_t key[SORT_E];
-                init_keys4(P, i0, bits, key);
+        {
+            uint32_t *mine = sub + (tid & 7u) * 1024u;
+            for (uint32_t t0 = 0; t0 < n; t0 += SORT_NT * SORT_E) {
+                const uint32_t i0 = t0 + tid * SORT_E;          // SORT_E consecutive rotations per lane, one window of P
+                if (i0 < n) {
+                    uint32_t key[SORT_E];
+                    init_keys4(P, i0, bits, key);
 #pragma unroll
-                for (int e = 0; e < SORT_E; e++) {
-                    if (i0 + e < n) {
-                        // packed symbol keys spread over the digits: plain LDS atomics (no wave aggregation needed)
+                    for (int e = 0; e < SORT_E; e++) {
+                        if (i0 + e < n) {
 #pragma unroll
-                        for (int p = 0; p < 4; p++) atomicAdd(&s_hist[p][(key[e] >> (8 * p)) & 255u], 1u);
+                            for (int p = 0; p < 4; p++) atomicAdd(&mine[p * 256 + ((key[e] >> (8 * p)) & 255u)], 1u);
+                        }
                     }
                 }
             }
+        }
+        __syncthreads();
+        {
+            uint32_t t = 0;                               // tid = digit position * 256 + digit value
+#pragma unroll
+            for (int c = 0; c < 8; c++) t += sub[c * 1024 + tid];
+            (&s_hist[0][0])[tid] = t;
         }
         __syncthreads();
         PHASE_STAMP(0);
