@@ -6,8 +6,9 @@
 // (sais_fallback.rs:469-578); neither maps to a GPU.  Here one workgroup (1024 lanes) sorts one
 // block, keeping only the rotations that are still tied ("unresolved") from round to round:
 //
-//   A   bytes in use -> dense symbol ids of `bits` bits (a 32-bit key then holds ksym symbols plus the top
-//       bits of the next one; a 64-bit round key holds csym symbols)
+//   A   bytes in use -> dense symbol ids of `bits` bits; the block is packed once into a bit string P, and every
+//       key is one shifted 8-byte window of P (32-bit initial key = 32/bits symbols + the top of the next one,
+//       round key = the next csym = 56/bits symbols)
 //   I   records [key:32 | i:20 | preceding byte:8], built from the block by the first of four stable
 //       8-bit LSD radix passes (per-wave LDS digit masks and counters, LDS-staged coalesced scatter)     (n each)
 //   R   re-rank: group boundaries, SA[pos] = sa, L[pos] = preceding byte, compaction of the
@@ -16,8 +17,7 @@
 //       groups larger than a tile are split by single symbols (counting sorts inside the group's range);
 //       groups that resist are FROZEN for the RANK rounds; then each wave sorts tiles of <= 256 records,
 //       cut at group boundaries, by (g, next csym symbols at sa+depth) with a register / cross-lane
-//       bitonic network.  No ISA exists in this mode: the only random accesses are 8-byte reads of the
-//       block itself.                                                                                    (m)
+//       bitonic network.  No ISA exists in this mode: the only random accesses are 8-byte reads of P.   (m)
 //   RANK rounds (only for deep repeats; h doubles): ISA is built once from SA (radix pass + LDS windows),
 //       key2 = ISA[(sa+h) mod n]; oversized groups are split by the digits of key2, wave tiles of <= 512
 //       records finish the order; R writes ISA where a rank changed.                                    (m)
