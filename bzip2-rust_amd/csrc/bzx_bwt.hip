@@ -239,19 +239,23 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
 
     int cur = 0;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    // software pipeline: the records of tile t+1 are loaded while tile t is ranked and scattered; the
+    // software pipeline: the records of tiles t+1 and t+2 are loaded while tile t is ranked and scattered; the
     // barriers inside the loop order LDS only, so those loads (and the scatter stores) stay in flight.
-    uint64_t nxt[SORT_E];
+    uint64_t nxt[SORT_E], nxt2[SORT_E];         // one and two tiles ahead
     {
         const uint32_t wbase = wave * (64 * SORT_E);
         if (SRC == SRC_TEXT) {
             const uint32_t i0 = wbase + lane * SORT_E;
             init_records4(T, P, m, i0 < m ? i0 : 0u, i0 >= m ? 0u : (m - i0 < SORT_E ? m - i0 : (uint32_t)SORT_E), bits, nxt);
+            const uint32_t i2 = i0 + SORT_NT * SORT_E;
+            init_records4(T, P, m, i2 < m ? i2 : 0u, i2 >= m ? 0u : (m - i2 < SORT_E ? m - i2 : (uint32_t)SORT_E), bits, nxt2);
         } else {
 #pragma unroll
             for (int e = 0; e < SORT_E; e++) {
                 const uint32_t idx = wbase + e * 64 + lane;
                 nxt[e] = idx < m ? radix_source<SRC>(src, idx, m, T, bits, P) : 0ull;
+                const uint32_t id2 = idx + SORT_NT * SORT_E;
+                nxt2[e] = id2 < m ? radix_source<SRC>(src, id2, m, T, bits, P) : 0ull;
             }
         }
     }
@@ -260,17 +264,20 @@ __device__ __attribute__((noinline)) void radix_pass(const uint64_t *__restrict_
         uint64_t rec[SORT_E];
         uint32_t off[SORT_E], dig[SORT_E];
 #pragma unroll
-        for (int e = 0; e < SORT_E; e++) rec[e] = nxt[e];
+        for (int e = 0; e < SORT_E; e++) {
+            rec[e] = nxt[e];
+            nxt[e] = nxt2[e];
+        }
         {
-            const uint32_t nbase = wbase + SORT_NT * SORT_E;
+            const uint32_t nbase = wbase + 2 * SORT_NT * SORT_E;
             if (SRC == SRC_TEXT) {
                 const uint32_t i0 = nbase + lane * SORT_E;
-                init_records4(T, P, m, i0 < m ? i0 : 0u, i0 >= m ? 0u : (m - i0 < SORT_E ? m - i0 : (uint32_t)SORT_E), bits, nxt);
+                init_records4(T, P, m, i0 < m ? i0 : 0u, i0 >= m ? 0u : (m - i0 < SORT_E ? m - i0 : (uint32_t)SORT_E), bits, nxt2);
             } else {
 #pragma unroll
                 for (int e = 0; e < SORT_E; e++) {
                     const uint32_t idx = nbase + e * 64 + lane;
-                    nxt[e] = idx < m ? radix_source<SRC>(src, idx, m, T, bits, P) : 0ull;
+                    nxt2[e] = idx < m ? radix_source<SRC>(src, idx, m, T, bits, P) : 0ull;
                 }
             }
         }
@@ -399,13 +406,15 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
     }
     __syncthreads();
     uint32_t my_maxgrp = 0;
-    // software pipeline: the records of the next tile are loaded while this one is scanned and stored; the
+    // software pipeline: the records of the next two tiles are loaded while this one is scanned and stored; the
     // barriers of the loop order LDS only
-    uint64_t nx[SORT_E + 2];
+    uint64_t nx[SORT_E + 2], nx2[SORT_E + 2];   // one and two tiles ahead (two tiles of loads in flight per lane)
 #pragma unroll
     for (int j = 0; j < SORT_E + 2; j++) {
         const uint32_t kk = tid * SORT_E + j;   // nx[j] holds U[kk - 1]
         nx[j] = (kk >= 1 && kk - 1 < m) ? U[kk - 1] : 0ull;
+        const uint32_t k2 = kk + SORT_NT * SORT_E;
+        nx2[j] = (k2 - 1 < m) ? U[k2 - 1] : 0ull;
     }
     for (uint32_t t0 = 0; t0 < m; t0 += SORT_NT * SORT_E) {
         const uint32_t k0 = t0 + tid * SORT_E;
@@ -414,8 +423,9 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
 #pragma unroll
         for (int j = 0; j < SORT_E + 2; j++) {
             r[j] = nx[j];
-            const uint32_t kk = k0 + SORT_NT * SORT_E + j;
-            nx[j] = (kk - 1 < m) ? U[kk - 1] : 0ull;
+            nx[j] = nx2[j];
+            const uint32_t kk = k0 + 2 * SORT_NT * SORT_E + j;
+            nx2[j] = (kk - 1 < m) ? U[kk - 1] : 0ull;
         }
         bool f[SORT_E + 1];
 #pragma unroll
