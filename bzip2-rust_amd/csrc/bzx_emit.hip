@@ -69,6 +69,9 @@ struct BitW {
 __shared__ uint8_t e_len[6][BZX_MAX_ALPHA + 2];
 __shared__ uint32_t e_code[6][BZX_MAX_ALPHA + 2];
 __shared__ uint32_t e_cl[6][BZX_MAX_ALPHA + 2];     // code | length << 24: one lookup per payload symbol
+// one tile of payload symbols: EMIT_NT groups x 25 words, loaded coalesced, read back by group (stride 25 words: odd,
+// so the lanes of a wave hit different banks)
+__shared__ __attribute__((aligned(16))) uint32_t e_tile[EMIT_NT * (BZX_G_SIZE / 2)];
 __shared__ uint32_t e_tabbits[8];
 __shared__ uint32_t e_scratch[2 * EMIT_NW];
 __shared__ uint32_t e_bcast[4];
@@ -215,12 +218,21 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
                 const uint32_t gb = g < n_sel ? (uint32_t)GB[g] : 0u;
                 uint32_t tot;
                 const uint32_t ex = bzx_block_excl_sum<EMIT_NT>(gb, e_scratch, tot);
+                // the tile's symbols: coalesced 16-byte loads into LDS (the slab is longer than any block's symbols,
+                // so the last tile may read past n_mtf; such symbols are never coded)
+                {
+                    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(V + (size_t)g0 * BZX_G_SIZE);
+                    uint4 *dst = reinterpret_cast<uint4 *>(e_tile);
+                    const uint32_t ng = n_sel - g0 < EMIT_NT ? n_sel - g0 : EMIT_NT;
+                    const uint32_t nq = (ng * (BZX_G_SIZE / 2) + 3u) / 4u;          // 16-byte pieces
+                    for (uint32_t i = tid; i < nq; i += EMIT_NT) dst[i] = src[i];
+                }
+                __syncthreads();
                 if (g < n_sel) {
                     const uint32_t gs = g * BZX_G_SIZE;
                     const uint32_t cnt = (n_mtf - gs < BZX_G_SIZE) ? n_mtf - gs : BZX_G_SIZE;
-                    const uint32_t *__restrict__ vp = reinterpret_cast<const uint32_t *>(V + gs);
+                    const uint32_t *vp = e_tile + tid * (BZX_G_SIZE / 2);
                     const uint32_t *__restrict__ cl = e_cl[SEL[g]];
-                    // all loads of the group first (25 words in flight), then all table lookups, then the packing
                     uint32_t vw[BZX_G_SIZE / 2];
 #pragma unroll
                     for (uint32_t k = 0; k < BZX_G_SIZE / 2; k++) vw[k] = 2 * k < cnt ? vp[k] : 0u;
