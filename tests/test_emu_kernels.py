@@ -40,6 +40,17 @@ def test_emu_stages_small(emu, oracle):
         assert emu.compress_block(blk, crc) == oracle.compress_block(blk, crc)
 
 
+def test_emu_alphabet_sizes(emu, oracle):
+    """Symbol widths 1..8 bits of the packed block the sorter builds."""
+    rnd = random.Random(21)
+    for k in (1, 2, 3, 5, 9, 17, 33, 65, 129, 256):
+        syms = rnd.sample(range(256), k)
+        body = bytes(rnd.choices(syms, [1.0 / (i + 1) for i in range(k)], k=1800))
+        blk = body + body[:700] + bytes(rnd.choices(syms, k=500))
+        L, orig, _ = emu.stage_bwt(blk)
+        assert (L, orig) == oracle.bwt(blk), k
+
+
 def test_emu_split_and_stream(emu, oracle):
     rnd = random.Random(8)
     runs = bytearray()

@@ -172,6 +172,19 @@ def test_deep_repeats(bzx, oracle):
         assert bzx.compress_buffer(data, 9) == bz2.compress(data, 9)
 
 
+def test_alphabet_sizes(bzx, oracle):
+    """Every symbol width of the packed block (1..8 bits) and both sides of each power of two, on skewed and on
+    repetitive data (level 1: several blocks per input)."""
+    import random
+    rnd = random.Random(11)
+    for k in (1, 2, 3, 4, 5, 8, 9, 16, 17, 32, 33, 64, 65, 128, 129, 200, 256):
+        syms = rnd.sample(range(256), k)
+        weights = [1.0 / (i + 1) for i in range(k)]
+        body = bytes(rnd.choices(syms, weights, k=120000))
+        data = body + body[:40000] + bytes(rnd.choices(syms, k=60000)) + body[5000:65000]
+        assert bzx.compress_buffer(data, 1) == bz2.compress(data, 1), k
+
+
 def test_random_and_zero_heavy_inputs(bzx, oracle):
     """BASELINE configs[4] shapes at reduced size: incompressible bytes (sort worst case for MTF) and an
     all-zero input (RLE1-heavy, periodic blocks)."""
