@@ -42,7 +42,9 @@ struct bzx_ctx {
     bool own_stream = false;
     // second stream: MTF of finished blocks runs beside the last (partial) round of the sort
     hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bend = nullptr;
+    bool overlap_used = false;       // the last run launched the overlapped pair
+    bool overlap_off = false;        // ... and it turned out to be serialised on this device/runtime: do not try again
     uint32_t bwt_launches = 1;       // BWT kernel launches of the last run (telemetry)
     std::string err;
 
@@ -198,9 +200,14 @@ extern "C" int bzx_ctx_create(int device, uint32_t max_blocks, bzx_ctx **out)
     }
     ctx->own_stream = true;
     for (int i = 0; i < 8; i++) (void)hipEventCreate(&ctx->ev[i]);
-    if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+    // A stream of another priority gets a hardware queue of its own; with the default priority HIP may map it onto
+    // the queue of the caller's stream (it does once RCCL has created its streams), which would serialise the
+    // overlapped MTF launch behind the sort instead of running it beside it.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+        hipEventCreate(&ctx->ev_fork) != hipSuccess || hipEventCreate(&ctx->ev_join) != hipSuccess ||
+        hipEventCreate(&ctx->ev_bend) != hipSuccess) {
         bzx_ctx_destroy(ctx);
         return BZX_E_HIP;
     }
@@ -230,6 +237,7 @@ extern "C" void bzx_ctx_destroy(bzx_ctx *ctx)
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_bend) (void)hipEventDestroy(ctx->ev_bend);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -287,7 +295,8 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         // beside the MTF stage of blocks that are already sorted (second stream, exactly the idle units).
         const uint32_t ncu = (uint32_t)ctx->n_cu;
         const uint32_t rem = nblk % ncu, idle = ncu - rem;
-        if ((stages & STG_MTF) && per_cu == 1 && nblk > ncu && rem != 0 && idle * 8 >= ncu) {
+        ctx->overlap_used = false;
+        if ((stages & STG_MTF) && per_cu == 1 && nblk > ncu && rem != 0 && idle * 8 >= ncu && !ctx->overlap_off) {
             const uint32_t full = nblk - rem;
             const uint32_t n_a1 = full < idle * 6 ? full : idle * 6;      // a block sorts in roughly 6 MTF times
             BzxBatch Ba = B;
@@ -299,6 +308,8 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
             Bb.nblk = rem;
             Bb.ctr_bwt = 6;
             bzx_launch_bwt(Bb, rem, ctx->stream);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_bend, ctx->stream));
+            ctx->overlap_used = true;
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
             BzxBatch Bm = B;
             Bm.nblk = n_a1;
@@ -378,6 +389,17 @@ int bzx_ctx_ncu(bzx_ctx *ctx) { return ctx->n_cu; }
 
 static void collect_stage_times(bzx_ctx *ctx)
 {
+    // Did the overlapped MTF launch really run beside the partial sort round?  If the runtime put both streams on
+    // one hardware queue the MTF launch finished a whole launch time after the sort round instead of with it:
+    // then the split costs time, and later runs on this context use the plain order.
+    if (ctx->overlap_used) {
+        float t_sort = 0.f, t_join = 0.f;
+        if (hipEventElapsedTime(&t_sort, ctx->ev_fork, ctx->ev_bend) == hipSuccess &&
+            hipEventElapsedTime(&t_join, ctx->ev_fork, ctx->ev_join) == hipSuccess && t_sort > 0.f &&
+            t_join - t_sort > 0.6f * t_sort)
+            ctx->overlap_off = true;
+        ctx->overlap_used = false;
+    }
     float ms[4] = {0, 0, 0, 0};
     for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]);
     ctx->stats.ms_bwt = ms[0];

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "bzip2-rust_amd", "libbzx.so")
+LIB_PATH = os.environ.get("BZX_LIB", os.path.join(ROOT, "bzip2-rust_amd", "libbzx.so"))   # BZX_LIB: probe builds
 EMU_PATH = os.path.join(ROOT, "tests", "emu", "libbzx_emu.so")
 ORACLE_PATH = os.path.join(ROOT, "oracle", "libbzx_oracle.so")
 

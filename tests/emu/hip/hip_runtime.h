@@ -148,6 +148,8 @@ inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 #define hipStreamNonBlocking 1
 #define hipEventDisableTiming 2
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = 0; return 0; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = 0; return 0; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int *a, int *b) { *a = 0; *b = 0; return 0; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = 0; return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
