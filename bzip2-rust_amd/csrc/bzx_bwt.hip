@@ -540,7 +540,9 @@ __device__ __forceinline__ bool seg_less(const SegRec &a, const SegRec &b)
     return ga < gb || (ga == gb && (a.key < b.key || (a.key == b.key && a.rec < b.rec)));
 }
 
-template <bool TEXT, int SEG_PER_LANE> __device__ __forceinline__ void bitonic_tile(SegRec (&v)[SEG_PER_LANE], uint32_t lane)
+// CMP 0: RANK, the whole order lives in rec.  CMP 1: TEXT, (g, key, rec).  CMP 2: TEXT, key alone decides (it carries the
+// tile-local group index in its top byte); equal keys are never exchanged, so no tie-break is needed.
+template <int CMP, int SEG_PER_LANE> __device__ __forceinline__ void bitonic_tile(SegRec (&v)[SEG_PER_LANE], uint32_t lane)
 {
     constexpr uint32_t SEG_TILE = 64 * SEG_PER_LANE;
 #pragma unroll
@@ -556,10 +558,14 @@ template <bool TEXT, int SEG_PER_LANE> __device__ __forceinline__ void bitonic_t
                     const bool asc = (e & k) == 0;
                     SegRec o;
                     o.rec = __shfl_xor(v[j].rec, (int)lst);
-                    o.key = TEXT ? __shfl_xor(v[j].key, (int)lst) : 0ull;
+                    o.key = CMP ? __shfl_xor(v[j].key, (int)lst) : 0ull;
                     const bool keep_min = lower == asc;
-                    const bool mine_less = TEXT ? seg_less(v[j], o) : (v[j].rec < o.rec);
-                    if (mine_less != keep_min) v[j] = o;
+                    if (CMP == 2) {
+                        if (keep_min ? (o.key < v[j].key) : (o.key > v[j].key)) v[j] = o;
+                    } else {
+                        const bool mine_less = CMP ? seg_less(v[j], o) : (v[j].rec < o.rec);
+                        if (mine_less != keep_min) v[j] = o;
+                    }
                 }
             } else {
 #pragma unroll
@@ -568,8 +574,10 @@ template <bool TEXT, int SEG_PER_LANE> __device__ __forceinline__ void bitonic_t
                     if (pj > j) {
                         const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
                         const bool asc = (e & k) == 0;
-                        const bool less = TEXT ? seg_less(v[j], v[pj]) : (v[j].rec < v[pj].rec);
-                        if (less != asc) {
+                        bool swap;
+                        if (CMP == 2) swap = asc ? (v[j].key > v[pj].key) : (v[j].key < v[pj].key);
+                        else swap = (CMP ? seg_less(v[j], v[pj]) : (v[j].rec < v[pj].rec)) != asc;
+                        if (swap) {
                             const SegRec t = v[j];
                             v[j] = v[pj];
                             v[pj] = t;
@@ -693,7 +701,29 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
                 v[j].key = ~0ull;
             }
         }
-        bitonic_tile<TEXT, SEG_PER_LANE>(v, lane);
+        if (TEXT && bits < 8) {
+            // round keys of < 8-bit alphabets leave the top byte free: put the tile-local group index there and let
+            // the key alone order the tile (the records are in g order already, a group never spans tiles)
+            uint32_t cnt = 0, fl = 0;
+            const uint64_t pg = __shfl_up(v[SEG_PER_LANE - 1].rec, 1) >> G_SHIFT;
+#pragma unroll
+            for (int j = 0; j < SEG_PER_LANE; j++) {
+                const uint64_t before = j ? (v[j - 1].rec >> G_SHIFT) : pg;
+                const bool nw = !(lane == 0 && j == 0) && (v[j].rec >> G_SHIFT) != before;
+                cnt += nw;
+                fl |= (uint32_t)nw << j;
+            }
+            uint32_t lg = bzx_wave_incl_sum(cnt) - cnt;
+#pragma unroll
+            for (int j = 0; j < SEG_PER_LANE; j++) {
+                lg += (fl >> j) & 1u;
+                const uint32_t i = a + lane * SEG_PER_LANE + (uint32_t)j;
+                if (i < b) v[j].key |= (uint64_t)lg << 56;
+            }
+            bitonic_tile<2, SEG_PER_LANE>(v, lane);
+        } else {
+            bitonic_tile<TEXT ? 1 : 0, SEG_PER_LANE>(v, lane);
+        }
         if (TEXT) {
             // tile-local index of the first member of every new (g, key) group -> record bits 28..37
             SegRec pl;                                     // last element of the previous lane
