@@ -540,8 +540,7 @@ __device__ __forceinline__ bool seg_less(const SegRec &a, const SegRec &b)
     return ga < gb || (ga == gb && (a.key < b.key || (a.key == b.key && a.rec < b.rec)));
 }
 
-// CMP 0: RANK, the whole order lives in rec.  CMP 1: TEXT, (g, key, rec).  CMP 2: TEXT, key alone decides (it carries the
-// tile-local group index in its top byte); equal keys are never exchanged, so no tie-break is needed.
+// CMP 0: the whole order lives in rec (RANK records; TEXT composites of alphabets under 8 bits).  CMP 1: (g, key, rec).
 template <int CMP, int SEG_PER_LANE> __device__ __forceinline__ void bitonic_tile(SegRec (&v)[SEG_PER_LANE], uint32_t lane)
 {
     constexpr uint32_t SEG_TILE = 64 * SEG_PER_LANE;
@@ -560,12 +559,8 @@ template <int CMP, int SEG_PER_LANE> __device__ __forceinline__ void bitonic_til
                     o.rec = __shfl_xor(v[j].rec, (int)lst);
                     o.key = CMP ? __shfl_xor(v[j].key, (int)lst) : 0ull;
                     const bool keep_min = lower == asc;
-                    if (CMP == 2) {
-                        if (keep_min ? (o.key < v[j].key) : (o.key > v[j].key)) v[j] = o;
-                    } else {
-                        const bool mine_less = CMP ? seg_less(v[j], o) : (v[j].rec < o.rec);
-                        if (mine_less != keep_min) v[j] = o;
-                    }
+                    const bool mine_less = CMP ? seg_less(v[j], o) : (v[j].rec < o.rec);
+                    if (mine_less != keep_min) v[j] = o;
                 }
             } else {
 #pragma unroll
@@ -574,10 +569,7 @@ template <int CMP, int SEG_PER_LANE> __device__ __forceinline__ void bitonic_til
                     if (pj > j) {
                         const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
                         const bool asc = (e & k) == 0;
-                        bool swap;
-                        if (CMP == 2) swap = asc ? (v[j].key > v[pj].key) : (v[j].key < v[pj].key);
-                        else swap = (CMP ? seg_less(v[j], v[pj]) : (v[j].rec < v[pj].rec)) != asc;
-                        if (swap) {
+                        if ((CMP ? seg_less(v[j], v[pj]) : (v[j].rec < v[pj].rec)) != asc) {
                             const SegRec t = v[j];
                             v[j] = v[pj];
                             v[pj] = t;
@@ -702,8 +694,11 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
             }
         }
         if (TEXT && bits < 8) {
-            // round keys of < 8-bit alphabets leave the top byte free: put the tile-local group index there and let
-            // the key alone order the tile (the records are in g order already, a group never spans tiles)
+            // Alphabets under 8 bits: ONE 64-bit word per rotation goes through the network,
+            //   [tile-local group index:7 | round key:49 | position in the tile:8]
+            // (the records are in g order already and a group never spans tiles), i.e. half the cross-lane traffic
+            // of sorting (record, key) pairs; the records wait in LDS and are picked up by position afterwards.
+            uint64_t *park = s_stage + wave * SEG_TILE;
             uint32_t cnt = 0, fl = 0;
             const uint64_t pg = __shfl_up(v[SEG_PER_LANE - 1].rec, 1) >> G_SHIFT;
 #pragma unroll
@@ -714,31 +709,27 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
                 fl |= (uint32_t)nw << j;
             }
             uint32_t lg = bzx_wave_incl_sum(cnt) - cnt;
+            SegRec c[SEG_PER_LANE];
 #pragma unroll
             for (int j = 0; j < SEG_PER_LANE; j++) {
                 lg += (fl >> j) & 1u;
-                const uint32_t i = a + lane * SEG_PER_LANE + (uint32_t)j;
-                if (i < b) v[j].key |= (uint64_t)lg << 56;
+                const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
+                park[e] = v[j].rec;
+                c[j].rec = a + e < b ? ((uint64_t)lg << 57) | (v[j].key << 8) | (uint64_t)e : ~0ull;
+                c[j].key = 0;
             }
-            bitonic_tile<2, SEG_PER_LANE>(v, lane);
-        } else {
-            bitonic_tile<TEXT ? 1 : 0, SEG_PER_LANE>(v, lane);
-        }
-        if (TEXT) {
+            bitonic_tile<0, SEG_PER_LANE>(c, lane);
+            bzx_wave_sync();
             // tile-local index of the first member of every new (g, key) group -> record bits 28..37
-            SegRec pl;                                     // last element of the previous lane
-            pl.rec = __shfl_up(v[SEG_PER_LANE - 1].rec, 1);
-            pl.key = __shfl_up(v[SEG_PER_LANE - 1].key, 1);
-            uint32_t last = 0;                             // 1 + index of the last new-group start in my lane
-            uint32_t fl = 0;
+            const uint64_t pc = __shfl_up(c[SEG_PER_LANE - 1].rec, 1) >> 8;
+            uint32_t last = 0, nfl = 0;
 #pragma unroll
             for (int j = 0; j < SEG_PER_LANE; j++) {
-                const SegRec &p = j ? v[j - 1] : pl;
+                const uint64_t before = j ? (c[j - 1].rec >> 8) : pc;
                 const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
-                const bool nw = (e == 0) || (v[j].rec >> G_SHIFT) != (p.rec >> G_SHIFT) || v[j].key != p.key;
-                if (nw) {
+                if (e == 0 || (c[j].rec >> 8) != before) {
                     last = e + 1;
-                    fl |= 1u << j;
+                    nfl |= 1u << j;
                 }
             }
             const uint32_t incl = bzx_wave_incl_max(last);
@@ -747,8 +738,39 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
 #pragma unroll
             for (int j = 0; j < SEG_PER_LANE; j++) {
                 const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
-                if ((fl >> j) & 1u) run = e + 1;
-                v[j].rec |= (uint64_t)((run - 1) & 0x3FFu) << TXT_KEY_SHIFT;
+                if ((nfl >> j) & 1u) run = e + 1;
+                const uint64_t rec = a + e < b ? park[(uint32_t)c[j].rec & 255u] : ~0ull;
+                v[j].rec = rec | ((uint64_t)((run - 1) & 0x3FFu) << TXT_KEY_SHIFT);
+            }
+            bzx_wave_sync();
+        } else {
+            bitonic_tile<TEXT ? 1 : 0, SEG_PER_LANE>(v, lane);
+            if (TEXT) {
+                // tile-local index of the first member of every new (g, key) group -> record bits 28..37
+                SegRec pl;                                     // last element of the previous lane
+                pl.rec = __shfl_up(v[SEG_PER_LANE - 1].rec, 1);
+                pl.key = __shfl_up(v[SEG_PER_LANE - 1].key, 1);
+                uint32_t last = 0;                             // 1 + index of the last new-group start in my lane
+                uint32_t fl = 0;
+#pragma unroll
+                for (int j = 0; j < SEG_PER_LANE; j++) {
+                    const SegRec &p = j ? v[j - 1] : pl;
+                    const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
+                    const bool nw = (e == 0) || (v[j].rec >> G_SHIFT) != (p.rec >> G_SHIFT) || v[j].key != p.key;
+                    if (nw) {
+                        last = e + 1;
+                        fl |= 1u << j;
+                    }
+                }
+                const uint32_t incl = bzx_wave_incl_max(last);
+                uint32_t run = __shfl_up(incl, 1);
+                if (lane == 0) run = 0;
+#pragma unroll
+                for (int j = 0; j < SEG_PER_LANE; j++) {
+                    const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
+                    if ((fl >> j) & 1u) run = e + 1;
+                    v[j].rec |= (uint64_t)((run - 1) & 0x3FFu) << TXT_KEY_SHIFT;
+                }
             }
         }
 #pragma unroll
@@ -1065,7 +1087,8 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         uint32_t bits = 1;
         while ((1u << bits) < n_in_use) bits++;
         const uint32_t ksym = 32 / bits;                              // whole symbols in the 32-bit initial key
-        const uint32_t csym = bits == 8 ? 8u : 56u / bits;            // symbols in a round key (one 64-bit window of P)
+        const uint32_t csym = bits == 8 ? 8u : 49u / bits;            // symbols in a round key (one window of P; 49 bits
+                                                                      // leave room for the tile bookkeeping, see seg_sort_round)
         uint8_t *__restrict__ P = reinterpret_cast<uint8_t *>(ws.isa) + PK_OFFSET;
         pk_build(T, n, bits, P);
 
