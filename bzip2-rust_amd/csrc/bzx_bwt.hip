@@ -8,7 +8,7 @@
 //
 //   A   bytes in use -> dense symbol ids of `bits` bits; the block is packed once into a bit string P, and every
 //       key is one shifted 8-byte window of P (32-bit initial key = 32/bits symbols + the top of the next one,
-//       round key = the next csym = 56/bits symbols)
+//       round key = the next csym = 48/bits symbols)
 //   I   records [key:32 | i:20 | preceding byte:8], built from the block by the first of four stable
 //       8-bit LSD radix passes (per-wave LDS digit masks and counters, LDS-staged coalesced scatter)     (n each)
 //   R   re-rank: group boundaries, SA[pos] = sa, L[pos] = preceding byte, compaction of the
@@ -534,14 +534,9 @@ struct SegRec {
     uint64_t key;   // secondary key (TEXT: 8 text bytes; RANK: unused, key2 lives inside rec)
 };
 
-__device__ __forceinline__ bool seg_less(const SegRec &a, const SegRec &b)
-{
-    const uint64_t ga = a.rec >> G_SHIFT, gb = b.rec >> G_SHIFT;
-    return ga < gb || (ga == gb && (a.key < b.key || (a.key == b.key && a.rec < b.rec)));
-}
-
-// CMP 0: the whole order lives in rec (RANK records; TEXT composites of alphabets under 8 bits).  CMP 1: (g, key, rec).
-template <int CMP, int SEG_PER_LANE> __device__ __forceinline__ void bitonic_tile(SegRec (&v)[SEG_PER_LANE], uint32_t lane)
+// Sorts the 64 * SEG_PER_LANE words v[].rec of a wave (lane-major order) ascending: compare-exchange inside a lane for
+// strides below SEG_PER_LANE, across lanes (shuffles) above.  Values are distinct except for the all-ones padding.
+template <int SEG_PER_LANE> __device__ __forceinline__ void bitonic_tile(SegRec (&v)[SEG_PER_LANE], uint32_t lane)
 {
     constexpr uint32_t SEG_TILE = 64 * SEG_PER_LANE;
 #pragma unroll
@@ -555,12 +550,9 @@ template <int CMP, int SEG_PER_LANE> __device__ __forceinline__ void bitonic_til
                 for (int j = 0; j < SEG_PER_LANE; j++) {
                     const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
                     const bool asc = (e & k) == 0;
-                    SegRec o;
-                    o.rec = __shfl_xor(v[j].rec, (int)lst);
-                    o.key = CMP ? __shfl_xor(v[j].key, (int)lst) : 0ull;
+                    const uint64_t o = __shfl_xor(v[j].rec, (int)lst);
                     const bool keep_min = lower == asc;
-                    const bool mine_less = CMP ? seg_less(v[j], o) : (v[j].rec < o.rec);
-                    if (mine_less != keep_min) v[j] = o;
+                    if ((v[j].rec < o) != keep_min) v[j].rec = o;
                 }
             } else {
 #pragma unroll
@@ -569,10 +561,10 @@ template <int CMP, int SEG_PER_LANE> __device__ __forceinline__ void bitonic_til
                     if (pj > j) {
                         const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
                         const bool asc = (e & k) == 0;
-                        if ((CMP ? seg_less(v[j], v[pj]) : (v[j].rec < v[pj].rec)) != asc) {
-                            const SegRec t = v[j];
-                            v[j] = v[pj];
-                            v[pj] = t;
+                        if ((v[j].rec < v[pj].rec) != asc) {
+                            const uint64_t t = v[j].rec;
+                            v[j].rec = v[pj].rec;
+                            v[pj].rec = t;
                         }
                     }
                 }
@@ -693,9 +685,9 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
                 v[j].key = ~0ull;
             }
         }
-        if (TEXT && bits < 8) {
-            // Alphabets under 8 bits: ONE 64-bit word per rotation goes through the network,
-            //   [tile-local group index:7 | round key:49 | position in the tile:8]
+        if (TEXT) {
+            // ONE 64-bit word per rotation goes through the network,
+            //   [tile-local group index:8 | round key:48 | position in the tile:8]
             // (the records are in g order already and a group never spans tiles), i.e. half the cross-lane traffic
             // of sorting (record, key) pairs; the records wait in LDS and are picked up by position afterwards.
             uint64_t *park = s_stage + wave * SEG_TILE;
@@ -715,10 +707,10 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
                 lg += (fl >> j) & 1u;
                 const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
                 park[e] = v[j].rec;
-                c[j].rec = a + e < b ? ((uint64_t)lg << 57) | (v[j].key << 8) | (uint64_t)e : ~0ull;
+                c[j].rec = a + e < b ? ((uint64_t)lg << 56) | (v[j].key << 8) | (uint64_t)e : ~0ull;
                 c[j].key = 0;
             }
-            bitonic_tile<0, SEG_PER_LANE>(c, lane);
+            bitonic_tile<SEG_PER_LANE>(c, lane);
             bzx_wave_sync();
             // tile-local index of the first member of every new (g, key) group -> record bits 28..37
             const uint64_t pc = __shfl_up(c[SEG_PER_LANE - 1].rec, 1) >> 8;
@@ -744,34 +736,7 @@ __device__ __attribute__((noinline)) void seg_sort_round(uint64_t *__restrict__ 
             }
             bzx_wave_sync();
         } else {
-            bitonic_tile<TEXT ? 1 : 0, SEG_PER_LANE>(v, lane);
-            if (TEXT) {
-                // tile-local index of the first member of every new (g, key) group -> record bits 28..37
-                SegRec pl;                                     // last element of the previous lane
-                pl.rec = __shfl_up(v[SEG_PER_LANE - 1].rec, 1);
-                pl.key = __shfl_up(v[SEG_PER_LANE - 1].key, 1);
-                uint32_t last = 0;                             // 1 + index of the last new-group start in my lane
-                uint32_t fl = 0;
-#pragma unroll
-                for (int j = 0; j < SEG_PER_LANE; j++) {
-                    const SegRec &p = j ? v[j - 1] : pl;
-                    const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
-                    const bool nw = (e == 0) || (v[j].rec >> G_SHIFT) != (p.rec >> G_SHIFT) || v[j].key != p.key;
-                    if (nw) {
-                        last = e + 1;
-                        fl |= 1u << j;
-                    }
-                }
-                const uint32_t incl = bzx_wave_incl_max(last);
-                uint32_t run = __shfl_up(incl, 1);
-                if (lane == 0) run = 0;
-#pragma unroll
-                for (int j = 0; j < SEG_PER_LANE; j++) {
-                    const uint32_t e = lane * SEG_PER_LANE + (uint32_t)j;
-                    if ((fl >> j) & 1u) run = e + 1;
-                    v[j].rec |= (uint64_t)((run - 1) & 0x3FFu) << TXT_KEY_SHIFT;
-                }
-            }
+            bitonic_tile<SEG_PER_LANE>(v, lane);
         }
 #pragma unroll
         for (int j = 0; j < SEG_PER_LANE; j++) {
@@ -1087,7 +1052,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         uint32_t bits = 1;
         while ((1u << bits) < n_in_use) bits++;
         const uint32_t ksym = 32 / bits;                              // whole symbols in the 32-bit initial key
-        const uint32_t csym = bits == 8 ? 8u : 49u / bits;            // symbols in a round key (one window of P; 49 bits
+        const uint32_t csym = 48u / bits;                             // symbols in a round key (one window of P; 48 bits
                                                                       // leave room for the tile bookkeeping, see seg_sort_round)
         uint8_t *__restrict__ P = reinterpret_cast<uint8_t *>(ws.isa) + PK_OFFSET;
         pk_build(T, n, bits, P);

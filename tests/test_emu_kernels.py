@@ -51,6 +51,17 @@ def test_emu_alphabet_sizes(emu, oracle):
         assert (L, orig) == oracle.bwt(blk), k
 
 
+def test_emu_many_groups_per_tile(emu, oracle):
+    """Oversized groups that the symbol splitter turns into singletons: sort tiles with more than 128 groups."""
+    rnd = random.Random(3)
+    parts = [bytes([65 + p, 66 + p, 67 + p, 68 + p, i & 255, (i * 37 + p) & 255]) + rnd.randbytes(5)
+             for p in range(40) for i in range(300)]
+    rnd.shuffle(parts)
+    blk = b"".join(parts) + bytes(range(256))
+    L, orig, _ = emu.stage_bwt(blk)
+    assert (L, orig) == oracle.bwt(blk)
+
+
 def test_emu_split_and_stream(emu, oracle):
     rnd = random.Random(8)
     runs = bytearray()

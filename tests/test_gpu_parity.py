@@ -168,8 +168,44 @@ def test_deep_repeats(bzx, oracle):
     rec = rnd.randbytes(190)
     records = b"".join(rec + b"%010d" % (i * 7919) for i in range(4000))
     twice = oracle.synthtext(440000) * 2 + b"tail"        # every rotation has a twin 440,000 bytes away
-    for data in (bytes(copies), records, twice, bytes(copies) + records[:200000]):
+    # 40 four-byte prefixes x 300 occurrences with (almost) distinct next bytes: oversized groups that the symbol
+    # splitter turns into singletons, i.e. sort tiles with more than 128 groups (8-bit tile-local group index)
+    parts = [bytes([65 + p, 66 + p, 67 + p, 68 + p, i & 255, (i * 37 + p) & 255]) + rnd.randbytes(5)
+             for p in range(40) for i in range(300)]
+    rnd.shuffle(parts)
+    singles = b"".join(parts) + bytes(range(256))
+    for data in (bytes(copies), records, twice, bytes(copies) + records[:200000], singles):
         assert bzx.compress_buffer(data, 9) == bz2.compress(data, 9)
+
+
+def test_real_files_from_the_image(bzx):
+    """Real data (python sources: 7-bit text with deep repeats; shared objects: 8-bit, highly redundant fat binaries)
+    read from the system image -- the kind of input that synthetic generators miss."""
+    import glob
+
+    def collect(patterns, limit):
+        out, seen = bytearray(), set()
+        for pat in patterns:
+            for f in sorted(glob.glob(pat, recursive=True)):
+                rp = os.path.realpath(f)
+                if rp in seen or not os.path.isfile(rp):
+                    continue
+                seen.add(rp)
+                try:
+                    out += open(rp, "rb").read()
+                except OSError:
+                    continue
+                if len(out) >= limit:
+                    return bytes(out[:limit])
+        return bytes(out)
+
+    sets = [collect(["/usr/lib/python3*/**/*.py"], 6 << 20),
+            collect(["/opt/rocm/lib/*.so*", "/usr/lib/x86_64-linux-gnu/*.so*"], 16 << 20)]
+    if not any(len(d) > (1 << 20) for d in sets):
+        pytest.skip("no system files to read")
+    for data in sets:
+        if len(data) > (1 << 20):
+            assert bzx.compress_buffer(data, 9) == bz2.compress(data, 9)
 
 
 def test_alphabet_sizes(bzx, oracle):
