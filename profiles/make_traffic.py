@@ -1,5 +1,5 @@
 """Turns the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as gpurun requires) into
-profiles/traffic.json: average HBM bytes per dispatch of every kernel.
+profiles/traffic.json: HBM bytes per bench step of every kernel.
 
     python profiles/make_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> "<command profiled>"
 
@@ -14,30 +14,36 @@ from collections import defaultdict
 
 
 def per_kernel(path, counter):
+    """Counter total per bench step for every kernel (steps = dispatches of the once-per-step layout kernel).
+    Per step rather than per dispatch: the sort kernel is launched twice per step, and under counter collection
+    the profiler serialises kernels, so the library's overlap check falls back to one launch after the first step --
+    the per-step total is the same either way."""
     acc = defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+    steps = max(1, len(acc.get("bzx_layout_kernel", [])))
+    return {k: sum(v) / steps for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}, steps
 
 
 def main():
-    fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
-    write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
+    fetch, nf, steps = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write, _, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
-        kernels[k] = {"dispatches": nf.get(k, 0), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
-                      "hbm_bytes_corrected": int((2.0 * f + w) * 1024)}
+        kernels[k] = {"dispatches": nf.get(k, 0), "FETCH_SIZE_KiB_per_step": round(f, 1),
+                      "WRITE_SIZE_KiB_per_step": round(w, 1), "hbm_bytes_per_step": int((2.0 * f + w) * 1024)}
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), " + sys.argv[3],
-           "units": "counter values are KiB per dispatch (x1024 = bytes), averaged over the dispatches of a kernel; "
+           "steps": steps,
+           "units": "counter values are KiB (x1024 = bytes), summed over a kernel's dispatches and divided by the bench steps; "
                     "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> fetch "
                     "doubled; scattered 8-byte accesses are uncalibrated",
            "kernels": kernels,
-           "bzx_bwt_kernel_hbm_bytes_per_launch": kernels.get("bzx_bwt_kernel", {}).get("hbm_bytes_corrected")}
+           "bzx_bwt_kernel_hbm_bytes_per_step": kernels.get("bzx_bwt_kernel", {}).get("hbm_bytes_per_step")}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
     json.dump(out, open(path, "w"), indent=1)
-    print("wrote", path, out["bzx_bwt_kernel_hbm_bytes_per_launch"])
+    print("wrote", path, out["bzx_bwt_kernel_hbm_bytes_per_step"])
 
 
 if __name__ == "__main__":
