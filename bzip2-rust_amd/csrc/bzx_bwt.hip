@@ -446,6 +446,9 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
         bzx_block_scan_sum_max_lds<SORT_NT>(my_cnt, my_ks, s_scratch, cnt_excl, cnt_total, ks_excl, ks_total);
         uint32_t ks = ks_excl ? ks_excl : carry_ks;
         uint32_t o = carry_cnt + cnt_excl;
+        // first re-rank: position = index, so the rows of a lane's four records are adjacent: SA and L take one
+        // 16-byte and one 4-byte store instead of four 4-byte and four 1-byte stores
+        const bool vec = INITIAL && k0 + SORT_E <= m;
 #pragma unroll
         for (int j = 0; j < SORT_E; j++) {
             const uint32_t k = k0 + j;
@@ -464,7 +467,7 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
                     if (newrank != (uint32_t)(rec >> G_SHIFT) || (rec & RNK_MOVED)) ISA[sa] = newrank;
                     // RANK records carry no preceding byte: fetch it once, when the rotation's row is final
                     if (f[j] && f[j + 1]) L[pos] = T[sa ? sa - 1 : n - 1];
-                } else {
+                } else if (!vec) {
                     SA[pos] = sa;
                     L[pos] = (uint8_t)rec;
                 }
@@ -478,6 +481,18 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
                     o++;
                 }
             }
+        }
+        if (vec) {
+            uint32_t lw = 0;
+            uint4 sv;
+            sv.x = (uint32_t)(r[1] >> SA_SHIFT) & 0xFFFFFu;
+            sv.y = (uint32_t)(r[2] >> SA_SHIFT) & 0xFFFFFu;
+            sv.z = (uint32_t)(r[3] >> SA_SHIFT) & 0xFFFFFu;
+            sv.w = (uint32_t)(r[4] >> SA_SHIFT) & 0xFFFFFu;
+#pragma unroll
+            for (int j = 0; j < SORT_E; j++) lw |= ((uint32_t)r[j + 1] & 255u) << (8 * j);
+            *reinterpret_cast<uint4 *>(SA + k0) = sv;        // k0 is a multiple of 4, the arrays are 256-byte aligned
+            *reinterpret_cast<uint32_t *>(L + k0) = lw;
         }
         if (tid == 0) {
             if (ks_total) s_bcast[1] = ks_total;
