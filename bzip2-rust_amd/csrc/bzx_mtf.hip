@@ -385,6 +385,10 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         }
         __syncthreads();
         uint32_t hot0 = 0, hot1 = 0, hot2 = 0;      // RUNA, RUNB and symbol 2 (rank 1) counted in registers
+        // The symbols of a tile are collected in LDS (the recency lists are dead by now) and written to V as aligned
+        // 4-byte pairs by consecutive lanes, instead of one 2-byte store per symbol.  When the count so far is odd,
+        // the last symbol waits in stg[0] for the next tile: pend = carry_out & 1.
+        uint16_t *stg = reinterpret_cast<uint16_t *>(m_rec);
         // software pipeline: the rank bytes of the next tile are loaded while this one is scanned and emitted;
         // the barriers inside the loop order LDS only
         uint4 nxt = make_uint4(0, 0, 0, 0);
@@ -424,7 +428,8 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
             uint32_t cnt_total;
             const uint32_t cnt_excl = bzx_block_excl_sum_lds<MTF_NT>(my_cnt, m_scratch, cnt_total);
             // emit
-            uint32_t o = carry_out + cnt_excl;
+            const uint32_t pend = carry_out & 1u;
+            uint32_t o = pend + cnt_excl;               // index in stg; V index = carry_out - pend + index
             p1 = p1_in;
 #pragma unroll
             for (int k = 0; k < MTF_E; k++) {
@@ -436,23 +441,34 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
                         zr--;
                         for (;;) {
                             const uint32_t sym = zr & 1u;
-                            V[o++] = (uint16_t)sym;
+                            stg[o++] = (uint16_t)sym;
                             if (sym) hot1++; else hot0++;
                             if (zr < 2) break;
                             zr = (zr - 2) >> 1;
                         }
                     }
-                    V[o++] = (uint16_t)(r + 1);
+                    stg[o++] = (uint16_t)(r + 1);
                     if (r == 1) hot2++; else atomicAdd(&m_freq[r + 1], 1u);
                     p1 = i + 1;
                 }
             }
-            if (tid == 0) {
-                if (p1_total) m_bcast[1] = p1_total;
-                m_bcast[2] = carry_out + cnt_total;
-            }
             bzx_lds_barrier();
+            {
+                const uint32_t total = pend + cnt_total;
+                uint32_t *dst = reinterpret_cast<uint32_t *>(V + (carry_out - pend));
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(stg);
+                for (uint32_t q = tid; q < (total >> 1); q += MTF_NT) dst[q] = src[q];
+                const uint16_t left = stg[total ? total - 1 : 0];
+                if (tid == 0) {
+                    if (p1_total) m_bcast[1] = p1_total;
+                    m_bcast[2] = carry_out + cnt_total;
+                }
+                bzx_lds_barrier();
+                if (tid == 0 && (total & 1u)) stg[0] = left;
+            }
         }
+        __syncthreads();
+        if (tid == 0 && (m_bcast[2] & 1u)) V[m_bcast[2] - 1] = stg[0];      // the symbol still waiting for a partner
         if (hot0) atomicAdd(&m_freq[0], hot0);
         if (hot1) atomicAdd(&m_freq[1], hot1);
         if (hot2) atomicAdd(&m_freq[2], hot2);
