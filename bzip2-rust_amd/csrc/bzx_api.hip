@@ -8,6 +8,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -35,11 +38,30 @@ void bzx_launch_pack_layout(const BzxBatch &B, uint32_t first, uint32_t step, ui
 void bzx_launch_unpack(const BzxBatch &B, const uint32_t *packed, uint32_t first, uint32_t step, uint32_t nown,
                        uint32_t grid, hipStream_t stream);
 
+struct BlockReq {
+    const uint8_t *blk;
+    size_t n;
+    uint32_t crc;
+    uint8_t *out;
+    size_t cap;
+    size_t out_len = 0;
+    uint8_t pad = 0;
+    int rc = 0;
+    bool done = false;
+};
+
 struct bzx_ctx {
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // Calls on one context from several host threads are serialised (api_mu); bzx_compress_block calls that arrive
+    // together (the reference's rayon workers, compress.rs:125-132) are collected into one device batch (bq_*).
+    std::recursive_mutex api_mu;
+    std::mutex bq_mu;
+    std::condition_variable bq_cv;
+    std::vector<struct BlockReq *> bq_pending;
+    bool bq_leader = false;
     // second stream: MTF of finished blocks runs beside the last (partial) round of the sort
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bend = nullptr;
@@ -418,6 +440,8 @@ static int check_blk_args(const uint8_t *p, size_t n)
 extern "C" int bzx_stage_bwt(bzx_ctx *ctx, const uint8_t *blk, size_t n, uint8_t *bwt_out, uint32_t *orig_ptr,
                              uint32_t *status)
 {
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !bwt_out || !orig_ptr || check_blk_args(blk, n)) return BZX_E_PARAM;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = ensure_blocks(ctx, 1);
@@ -441,6 +465,8 @@ extern "C" int bzx_stage_bwt(bzx_ctx *ctx, const uint8_t *blk, size_t n, uint8_t
 // given stages, return the HIP-event time of each stage in ms[4] (bwt, mtf, huffman, emit).
 extern "C" int bzx_dbg_time_stages(bzx_ctx *ctx, const uint8_t *blk, size_t n, uint32_t reps, int stages, float ms[4])
 {
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || check_blk_args(blk, n) || reps == 0) return BZX_E_PARAM;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = ensure_blocks(ctx, reps);
@@ -465,6 +491,8 @@ extern "C" int bzx_dbg_time_stages(bzx_ctx *ctx, const uint8_t *blk, size_t n, u
 extern "C" int bzx_stage_mtf(bzx_ctx *ctx, const uint8_t *bwt, size_t n, uint16_t *mtfv_out, uint32_t *n_mtf,
                              uint32_t freq_out[258], uint8_t in_use_out[256])
 {
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !mtfv_out || !n_mtf || !freq_out || !in_use_out || check_blk_args(bwt, n)) return BZX_E_PARAM;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = ensure_blocks(ctx, 1);
@@ -493,6 +521,8 @@ extern "C" int bzx_stage_huffman(bzx_ctx *ctx, const uint16_t *mtfv, uint32_t n_
                                  uint32_t alpha_size, uint32_t *n_groups, uint32_t *n_selectors, uint8_t *selectors,
                                  uint8_t len_out[6][258], uint32_t code_out[6][258])
 {
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !mtfv || !freq || !n_groups || !n_selectors || !selectors || !len_out || !code_out) return BZX_E_PARAM;
     if (n_mtf == 0 || n_mtf > BZX_MAX_BLOCK + 1 || alpha_size < 3 || alpha_size > BZX_MAX_ALPHA) return BZX_E_PARAM;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -535,6 +565,8 @@ extern "C" int bzx_compress_blocks(bzx_ctx *ctx, uint32_t nblk, const uint8_t *c
                                    const uint32_t *crcs, uint8_t *const *outs, const size_t *caps, size_t *out_lens,
                                    uint8_t *pads)
 {
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !blks || !ns || !crcs || !outs || !caps || !out_lens || !pads) return BZX_E_PARAM;
     if (nblk == 0) return BZX_OK;
     for (uint32_t b = 0; b < nblk; b++)
@@ -592,10 +624,62 @@ extern "C" int bzx_compress_blocks(bzx_ctx *ctx, uint32_t nblk, const uint8_t *c
     return ret;
 }
 
+// compress_block.rs:24.  Thread-safe: the reference calls compress_block from every rayon worker at once
+// (compress.rs:125-132).  The first caller becomes the batch leader, waits a moment for the others, runs all pending
+// blocks as ONE device batch and hands the results back; callers that arrive meanwhile form the next batch.
 extern "C" int bzx_compress_block(bzx_ctx *ctx, const uint8_t *blk, size_t n, uint32_t crc, uint8_t *out, size_t cap,
                                   size_t *out_len, uint8_t *pad_bits)
 {
-    return bzx_compress_blocks(ctx, 1, &blk, &n, &crc, &out, &cap, out_len, pad_bits);
+    if (!ctx || !out || !out_len || !pad_bits || check_blk_args(blk, n)) return BZX_E_PARAM;
+    BlockReq rq;
+    rq.blk = blk;
+    rq.n = n;
+    rq.crc = crc;
+    rq.out = out;
+    rq.cap = cap;
+    std::unique_lock<std::mutex> lk(ctx->bq_mu);
+    ctx->bq_pending.push_back(&rq);
+    while (!rq.done) {
+        if (ctx->bq_leader) {
+            ctx->bq_cv.wait(lk);
+            continue;
+        }
+        ctx->bq_leader = true;
+        ctx->bq_cv.wait_for(lk, std::chrono::microseconds(300));          // collection window (lock released)
+        std::vector<BlockReq *> batch;
+        batch.swap(ctx->bq_pending);
+        lk.unlock();
+        const uint32_t nb = (uint32_t)batch.size();
+        std::vector<const uint8_t *> blks(nb);
+        std::vector<size_t> ns(nb), caps(nb), lens(nb, 0);
+        std::vector<uint32_t> crcs(nb);
+        std::vector<uint8_t *> outs(nb);
+        std::vector<uint8_t> pads(nb, 0);
+        for (uint32_t i = 0; i < nb; i++) {
+            blks[i] = batch[i]->blk;
+            ns[i] = batch[i]->n;
+            crcs[i] = batch[i]->crc;
+            outs[i] = batch[i]->out;
+            caps[i] = batch[i]->cap;
+        }
+        const int rc = nb ? bzx_compress_blocks(ctx, nb, blks.data(), ns.data(), crcs.data(), outs.data(), caps.data(),
+                                                lens.data(), pads.data())
+                          : BZX_OK;
+        lk.lock();
+        for (uint32_t i = 0; i < nb; i++) {
+            BlockReq *q = batch[i];
+            q->out_len = lens[i];
+            q->pad = pads[i];
+            // a block whose image did not fit reports that; its neighbours in the batch are fine
+            q->rc = rc == BZX_E_OUTBUF ? (lens[i] > caps[i] ? BZX_E_OUTBUF : BZX_OK) : rc;
+            q->done = true;
+        }
+        ctx->bq_leader = false;
+        ctx->bq_cv.notify_all();
+    }
+    *out_len = rq.out_len;
+    *pad_bits = rq.pad;
+    return rq.rc;
 }
 
 static int level_ok(int level) { return level >= 1 && level <= 9; }
@@ -649,6 +733,8 @@ static void fill_stats_from_blocks(bzx_ctx *ctx, uint32_t nblk, uint64_t raw_byt
 extern "C" int bzx_compress_device(bzx_ctx *ctx, const void *d_raw, size_t len, int level, void *d_out, size_t cap,
                                    size_t *out_len)
 {
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !d_out || !out_len || !level_ok(level) || (len && !d_raw)) return BZX_E_PARAM;
     if (((uintptr_t)d_raw & 15u) || ((uintptr_t)d_out & 3u) || cap < 16) return BZX_E_PARAM;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -674,6 +760,8 @@ extern "C" int bzx_compress_device(bzx_ctx *ctx, const void *d_raw, size_t len, 
 extern "C" int bzx_compress_buffer(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level, uint8_t *out, size_t cap,
                                    size_t *out_len)
 {
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !out || !out_len || !level_ok(level) || (len && !raw)) return BZX_E_PARAM;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     void *d_raw = nullptr, *d_out = nullptr;
@@ -700,6 +788,8 @@ extern "C" int bzx_compress_buffer(bzx_ctx *ctx, const uint8_t *raw, size_t len,
 extern "C" int bzx_split_rle1(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level, uint8_t *blocks_out,
                               uint32_t nblk_cap, uint32_t *ns, uint32_t *crcs, uint32_t *nblk_out)
 {
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !blocks_out || !ns || !crcs || !nblk_out || !level_ok(level) || (len && !raw)) return BZX_E_PARAM;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     *nblk_out = 0;
@@ -741,6 +831,8 @@ extern "C" int bzx_split_rle1(bzx_ctx *ctx, const uint8_t *raw, size_t len, int 
 extern "C" int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, int level, uint32_t rank, uint32_t world,
                                  uint32_t *nblk_total, long long *d_bits, size_t bits_cap)
 {
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !nblk_total || !d_bits || !level_ok(level) || world == 0 || rank >= world || (len && !d_raw)) return BZX_E_PARAM;
     if ((uintptr_t)d_raw & 15u) return BZX_E_PARAM;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -771,6 +863,8 @@ extern "C" int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, in
 
 extern "C" int bzx_ctx_sync(bzx_ctx *ctx)
 {
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx) return BZX_E_PARAM;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -785,6 +879,8 @@ static uint32_t shard_count(uint32_t nblk, uint32_t rank, uint32_t world)
 extern "C" int bzx_shard_emit_packed(bzx_ctx *ctx, const long long *d_bits_all, void *d_packed, size_t cap,
                                      size_t *packed_len, size_t *stream_len)
 {
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !d_bits_all || !d_packed || !packed_len || !stream_len || ((uintptr_t)d_packed & 3u)) return BZX_E_PARAM;
     if (ctx->shard_level == 0) return BZX_E_STATE;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -847,6 +943,8 @@ extern "C" int bzx_shard_emit_packed(bzx_ctx *ctx, const long long *d_bits_all, 
 
 extern "C" int bzx_shard_assemble_begin(bzx_ctx *ctx, void *d_out, size_t cap, size_t *stream_len)
 {
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !d_out || ((uintptr_t)d_out & 3u)) return BZX_E_PARAM;
     if (ctx->shard_level == 0) return BZX_E_STATE;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -869,6 +967,8 @@ extern "C" int bzx_shard_assemble_begin(bzx_ctx *ctx, void *d_out, size_t cap, s
 
 extern "C" int bzx_shard_assemble_rank(bzx_ctx *ctx, const void *d_packed_r, uint32_t r, void *d_out)
 {
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !d_packed_r || !d_out || ((uintptr_t)d_packed_r & 3u) || r >= ctx->shard_world) return BZX_E_PARAM;
     if (ctx->shard_level == 0) return BZX_E_STATE;
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -57,6 +57,10 @@ int bzx_ctx_set_stream(bzx_ctx *ctx, void *hip_stream);
  * bit, origPtr, symbol map, selectors, coding tables, payload), last byte zero padded;
  * *pad_bits = number of pad bits (0..7), i.e. BitPacker::padding (bitpacker.rs:20-21).
  * Host pointers.  cap >= n + n/50 + 1024 is always enough.
+ * Thread-safe and re-entrant like the Rust function: the reference calls it from every rayon worker at once
+ * (compress.rs:125-132).  Calls that arrive together on one context are collected into one device batch (the
+ * first caller leads it, the others block until their block is done); a lone caller pays a 0.3 ms window.
+ * All other entry points of a context are serialised against each other by an internal lock.
  */
 int bzx_compress_block(bzx_ctx *ctx, const uint8_t *blk, size_t n, uint32_t crc, uint8_t *out, size_t cap,
                        size_t *out_len, uint8_t *pad_bits);

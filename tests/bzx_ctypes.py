@@ -122,7 +122,14 @@ class BzxLib:
         return [(outs[i].raw[:p_len[i]], p_pad[i]) for i in range(nb)]
 
     def compress_block(self, blk: bytes, crc: int):
-        return self.compress_blocks([blk], [crc])[0]
+        """The per-block entry point itself (compress_block.rs:24); safe to call from several threads at once."""
+        cap = len(blk) + len(blk) // 50 + 1024
+        out = C.create_string_buffer(cap)
+        ol, pad = C.c_size_t(), C.c_uint8()
+        self.lib.bzx_compress_block.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t,
+                                                C.POINTER(C.c_size_t), C.POINTER(C.c_uint8)]
+        self._check(self.lib.bzx_compress_block(self.ctx, blk, len(blk), crc, out, cap, C.byref(ol), C.byref(pad)))
+        return out.raw[:ol.value], pad.value
 
     def compress_buffer(self, data: bytes, level=9):
         cap = len(data) + len(data) // 50 + 4096

@@ -62,6 +62,26 @@ def test_emu_many_groups_per_tile(emu, oracle):
     assert (L, orig) == oracle.bwt(blk)
 
 
+def test_emu_concurrent_compress_block(emu, oracle):
+    """bzx_compress_block from several host threads on one context (the reference calls compress_block from every
+    rayon worker, compress.rs:125-132): calls are collected into device batches, every caller gets its own result."""
+    import threading
+    rnd = random.Random(17)
+    blocks = [oracle.synthtext(900 + 137 * i) if i % 3 else rnd.randbytes(700 + 91 * i) for i in range(12)]
+    want = [oracle.compress_block(b, oracle.crc32(b)) for b in blocks]
+    got = [None] * len(blocks)
+
+    def work(i):
+        got[i] = emu.compress_block(blocks[i], oracle.crc32(blocks[i]))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(blocks))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert got == want
+
+
 def test_emu_split_and_stream(emu, oracle):
     rnd = random.Random(8)
     runs = bytearray()

@@ -66,6 +66,30 @@ def test_compress_block(bzx, oracle):
         assert bzx.compress_block(blk, crc) == oracle.compress_block(blk, crc), name
 
 
+def test_compress_block_from_many_threads(bzx, oracle):
+    """The reference's calling pattern (compress.rs:125-132): compress_block from every worker thread at once, one
+    context.  The library batches concurrent calls; every caller must get its own block image."""
+    import threading
+    rnd = random.Random(23)
+    blocks = [oracle.synthtext(200000 + 1000 * i) if i % 4 else rnd.randbytes(150000 + 777 * i) for i in range(48)]
+    crcs = [oracle.crc32(b) for b in blocks]
+    got = [None] * len(blocks)
+    biggest = [0]
+
+    def work(i):
+        got[i] = bzx.compress_block(blocks[i], crcs[i])
+        biggest[0] = max(biggest[0], bzx.stats().nblk)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(blocks))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    for i, b in enumerate(blocks):
+        assert got[i] == oracle.compress_block(b, crcs[i]), i
+    assert biggest[0] > 1          # concurrent calls really shared a device batch
+
+
 def test_compress_blocks_batched(bzx, oracle):
     """Batched form (compress.rs:125-132): many ragged blocks at once, more blocks than CUs*slots is fine."""
     rnd = random.Random(5)
