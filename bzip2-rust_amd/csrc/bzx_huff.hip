@@ -121,7 +121,7 @@ __device__ void make_code_lengths(int t, int32_t alpha, int32_t max_len)
         }                                                                     \
     } while (0)
 
-__global__ __launch_bounds__(HUF_NT) void bzx_huff_kernel(BzxBatch B)
+__global__ __launch_bounds__(HUF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void bzx_huff_kernel(BzxBatch B)
 {
     const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
     unsigned long long t_last = 0;
