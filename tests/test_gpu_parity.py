@@ -244,6 +244,17 @@ def test_structured_fuzz_slice(bzx):
         assert bzx.compress_buffer(data, level) == bz2.compress(data, level), c
 
 
+def test_block_boundary_fuzz_slice(bzx):
+    """A fixed slice of tests/gpu_probe_fuzz_big.py: 0.1-4 MB inputs at all levels, long runs across block
+    boundaries, inputs that end at or just past a full block."""
+    from gpu_probe_fuzz_big import big
+    for c in range(40):
+        rnd = random.Random(5 * 7919 + c)
+        data = big(rnd)
+        level = rnd.randrange(1, 10)
+        assert bzx.compress_buffer(data, level) == bz2.compress(data, level), c
+
+
 def test_alphabet_sizes(bzx, oracle):
     """Every symbol width of the packed block (1..8 bits) and both sides of each power of two, on skewed and on
     repetitive data (level 1: several blocks per input)."""
