@@ -14,7 +14,7 @@ def collect(patterns, limit):
                 rp = os.path.realpath(f)
                 if rp in seen or os.path.isdir(rp): continue
                 seen.add(rp)
-                out += open(rp, "rb").read()
+                out += open(rp, "rb").read(limit - len(out))
             except Exception: pass
             if len(out) >= limit: return bytes(out[:limit])
     return bytes(out)

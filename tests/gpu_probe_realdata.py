@@ -12,7 +12,7 @@ def collect(patterns, limit):
                 if rp in seen or os.path.isdir(rp):
                     continue
                 seen.add(rp)
-                out += open(rp, "rb").read()
+                out += open(rp, "rb").read(limit - len(out))
             except Exception:
                 pass
             if len(out) >= limit:
