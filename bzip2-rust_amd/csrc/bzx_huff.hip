@@ -22,8 +22,8 @@
 
 __shared__ uint32_t h_freq[BZX_MAX_ALPHA + 2];
 __shared__ uint8_t h_len[6][BZX_MAX_ALPHA + 2];
-__shared__ uint32_t h_lenA[BZX_MAX_ALPHA + 2];   // len0 | len1<<10 | len2<<20
-__shared__ uint32_t h_lenB[BZX_MAX_ALPHA + 2];   // len3 | len4<<10 | len5<<20
+// per symbol, ONE 8-byte word: low half len0 | len1<<10 | len2<<20, high half len3 | len4<<10 | len5<<20
+__shared__ uint2 h_lenAB[BZX_MAX_ALPHA + 2];
 __shared__ uint32_t h_rfreq[6][BZX_MAX_ALPHA + 2];
 __shared__ int32_t h_heap[6][BZX_MAX_ALPHA + 2];
 __shared__ int32_t h_weight[6][BZX_MAX_ALPHA * 2];
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(HUF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         for (int iter = 0; iter < BZX_N_ITERS; iter++) {
             for (uint32_t i = tid; i < 6 * (BZX_MAX_ALPHA + 2); i += HUF_NT) (&h_rfreq[0][0])[i] = 0;
             for (uint32_t v = tid; v < BZX_MAX_ALPHA + 2; v += HUF_NT) {
-                h_lenA[v] = (uint32_t)h_len[0][v] | ((uint32_t)h_len[1][v] << 10) | ((uint32_t)h_len[2][v] << 20);
-                h_lenB[v] = (uint32_t)h_len[3][v] | ((uint32_t)h_len[4][v] << 10) | ((uint32_t)h_len[5][v] << 20);
+                h_lenAB[v] = make_uint2((uint32_t)h_len[0][v] | ((uint32_t)h_len[1][v] << 10) | ((uint32_t)h_len[2][v] << 20),
+                                        (uint32_t)h_len[3][v] | ((uint32_t)h_len[4][v] << 10) | ((uint32_t)h_len[5][v] << 20));
             }
             __syncthreads();
             for (uint32_t g = tid; g < n_sel; g += HUF_NT) {
@@ -199,8 +199,9 @@ __global__ __launch_bounds__(HUF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                 for (int k = 0; k < BZX_G_SIZE; k++) {
                     if ((uint32_t)k < cnt) {
                         const uint32_t s = (sy[k >> 1] >> (16 * (k & 1))) & 0xffffu;
-                        accA += h_lenA[s];
-                        accB += h_lenB[s];
+                        const uint2 l2 = h_lenAB[s];
+                        accA += l2.x;
+                        accB += l2.y;
                     }
                 }
                 const uint32_t cost[6] = {accA & 1023u, (accA >> 10) & 1023u, (accA >> 20) & 1023u,
@@ -261,8 +262,8 @@ __global__ __launch_bounds__(HUF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             B.code[(size_t)b * 6 * 260 + i] = live ? h_code[t][v] : 0u;
         }
         for (uint32_t v = tid; v < BZX_MAX_ALPHA + 2; v += HUF_NT) {
-            h_lenA[v] = (uint32_t)h_len[0][v] | ((uint32_t)h_len[1][v] << 10) | ((uint32_t)h_len[2][v] << 20);
-            h_lenB[v] = (uint32_t)h_len[3][v] | ((uint32_t)h_len[4][v] << 10) | ((uint32_t)h_len[5][v] << 20);
+            h_lenAB[v] = make_uint2((uint32_t)h_len[0][v] | ((uint32_t)h_len[1][v] << 10) | ((uint32_t)h_len[2][v] << 20),
+                                    (uint32_t)h_len[3][v] | ((uint32_t)h_len[4][v] << 10) | ((uint32_t)h_len[5][v] << 20));
         }
         __syncthreads();
 
@@ -283,8 +284,9 @@ __global__ __launch_bounds__(HUF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                 for (int k = 0; k < BZX_G_SIZE; k++) {
                     if ((uint32_t)k < cnt) {
                         const uint32_t sm = (sy[k >> 1] >> (16 * (k & 1))) & 0xffffu;
-                        accA += h_lenA[sm];
-                        accB += h_lenB[sm];
+                        const uint2 l2 = h_lenAB[sm];
+                        accA += l2.x;
+                        accB += l2.y;
                     }
                 }
                 const uint32_t pick = bt < 3 ? accA : accB;
