@@ -35,6 +35,7 @@ void bzx_launch_bits_export(const BzxBatch &B, long long *bits, hipStream_t stre
 void bzx_launch_bits_import(const BzxBatch &B, const long long *bits, hipStream_t stream);
 void bzx_launch_pack_layout(const BzxBatch &B, uint32_t first, uint32_t step, uint32_t nown, uint64_t *d_total,
                             hipStream_t stream);
+void bzx_launch_zero_edges(const BzxBatch &B, const uint64_t *d_total, hipStream_t stream);
 void bzx_launch_unpack(const BzxBatch &B, const uint32_t *packed, uint32_t first, uint32_t step, uint32_t nown,
                        uint32_t grid, hipStream_t stream);
 
@@ -959,7 +960,7 @@ extern "C" int bzx_shard_assemble_begin(bzx_ctx *ctx, void *d_out, size_t cap, s
         ctx->err = "output buffer too small for the compressed stream";
         return BZX_E_OUTBUF;
     }
-    HIP_TRY(ctx, hipMemsetAsync(d_out, 0, need, ctx->stream));
+    bzx_launch_zero_edges(B, ctx->d_scalars, ctx->stream);       // only the words that are OR-merged, not the whole stream
     bzx_launch_stream_frame(B, ctx->shard_level, ctx->d_scalars, ctx->d_scalars + 1, ctx->stream);
     if (stream_len) *stream_len = (size_t)out_bytes;
     return BZX_OK;

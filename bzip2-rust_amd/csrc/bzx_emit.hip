@@ -397,6 +397,28 @@ __global__ __launch_bounds__(256) void bzx_unpack_kernel(BzxBatch B, const uint3
     }
 }
 
+// Sharded assembly writes every interior word of a block image with a plain store; only the words that are merged
+// with atomicOr need to start from zero: the first and last word of every image, the header word and the first
+// and last word of the footer.  (Zeroing the whole stream instead costs a pass over gigabytes at N = 8.)
+__global__ __launch_bounds__(256) void bzx_zero_edges_kernel(BzxBatch B, const uint64_t *total)
+{
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B.nblk; b += gridDim.x * blockDim.x) {
+        const uint64_t ob = B.blk[b].out_bit, nb = B.blk[b].bits;
+        B.out[ob >> 5] = 0;
+        if (nb) B.out[(ob + nb - 1) >> 5] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint64_t end = total[0];
+        B.out[0] = 0;
+        for (uint64_t w = end >> 5; w <= (end + 79) >> 5; w++) B.out[w] = 0;
+    }
+}
+
+void bzx_launch_zero_edges(const BzxBatch &B, const uint64_t *d_total, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_zero_edges_kernel, dim3(64), dim3(256), 0, stream, B, d_total);
+}
+
 void bzx_launch_pack_layout(const BzxBatch &B, uint32_t first, uint32_t step, uint32_t nown, uint64_t *d_total,
                             hipStream_t stream)
 {
