@@ -399,13 +399,12 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
     constexpr int SA_SHIFT = (MODE == MODE_RANK) ? RNK_SA_SHIFT : TXT_SA_SHIFT;
     constexpr bool INITIAL = (MODE == MODE_INIT);
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) {
-        s_bcast[1] = 0;
-        s_bcast[2] = 0;
-        s_bcast[3] = 0;
-    }
+    if (tid == 0) s_bcast[3] = 0;
     __syncthreads();
     uint32_t my_maxgrp = 0;
+    // carries across tiles (last group start + 1, unresolved so far): every lane keeps them itself from the scan
+    // totals, so a tile costs the two barriers of the scan and nothing more
+    uint32_t carry_ks = 0, carry_cnt = 0;
     // software pipeline: the records of the next two tiles are loaded while this one is scanned and stored; the
     // barriers of the loop order LDS only
     uint64_t nx[SORT_E + 2], nx2[SORT_E + 2];   // one and two tiles ahead (two tiles of loads in flight per lane)
@@ -418,7 +417,6 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
     }
     for (uint32_t t0 = 0; t0 < m; t0 += SORT_NT * SORT_E) {
         const uint32_t k0 = t0 + tid * SORT_E;
-        const uint32_t carry_ks = s_bcast[1], carry_cnt = s_bcast[2];
         uint64_t r[SORT_E + 2];
 #pragma unroll
         for (int j = 0; j < SORT_E + 2; j++) {
@@ -494,17 +492,12 @@ __device__ __attribute__((noinline)) uint32_t rerank(const uint64_t *__restrict_
             *reinterpret_cast<uint4 *>(SA + k0) = sv;        // k0 is a multiple of 4, the arrays are 256-byte aligned
             *reinterpret_cast<uint32_t *>(L + k0) = lw;
         }
-        if (tid == 0) {
-            if (ks_total) s_bcast[1] = ks_total;
-            s_bcast[2] = carry_cnt + cnt_total;
-        }
-        bzx_lds_barrier();
+        if (ks_total) carry_ks = ks_total;
+        carry_cnt += cnt_total;
     }
     atomicMax(&s_bcast[3], my_maxgrp);
     __syncthreads();
-    const uint32_t res = s_bcast[2];
-    __syncthreads();
-    return res;
+    return carry_cnt;
 }
 
 // ISA[SA[j]] = j for every sorted position j (a permutation inversion).  A direct scatter writes 4 bytes into
