@@ -18,6 +18,8 @@
 #include "bzx_device.h"
 
 void bzx_launch_bwt(const BzxBatch &B, uint32_t grid, hipStream_t stream);
+void bzx_launch_bsplit(const BzxBatch &B, uint32_t grid, hipStream_t stream);
+void bzx_launch_bsort(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_periodic(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_mtf(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_huffman(const BzxBatch &B, uint32_t grid, hipStream_t stream);
@@ -31,6 +33,7 @@ int bzx_split_launch_boundaries(struct bzx_ctx *ctx, const uint8_t *d_raw, size_
 void bzx_split_launch_scatter(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, const BzxSplitWs &ws,
                               uint32_t nblk, uint8_t *d_slabs, BzxBlock *d_blk, uint32_t own_first, uint32_t own_step);
 uint32_t bzx_bwt_max_blocks_per_cu();
+uint32_t bzx_bsort_blocks_per_cu();
 void bzx_launch_bits_export(const BzxBatch &B, long long *bits, hipStream_t stream);
 void bzx_launch_bits_import(const BzxBatch &B, const long long *bits, hipStream_t stream);
 void bzx_launch_pack_layout(const BzxBatch &B, uint32_t first, uint32_t step, uint32_t nown, uint64_t *d_total,
@@ -66,9 +69,14 @@ struct bzx_ctx {
     // second stream: MTF of finished blocks runs beside the last (partial) round of the sort
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bend = nullptr;
+    hipEvent_t ev_b1 = nullptr, ev_b2 = nullptr;     // bucket sorter: after the split kernel, after the sort kernel
+    bool bsort_used = false;
+    uint32_t *h_counters = nullptr;                   // pinned copy of d_counters after a run
     bool overlap_used = false;       // the last run launched the overlapped pair
     bool overlap_off = false;        // ... and it turned out to be serialised on this device/runtime: do not try again
     uint32_t bwt_launches = 1;       // BWT kernel launches of the last run (telemetry)
+    bool use_bsort = true;           // bucket sorter (bzx_bsort.hip) first, general sorter for what it hands over;
+                                     // BZX_SORTER=general in the environment selects the general sorter alone
     std::string err;
 
     uint32_t cap_blocks = 0;   // per-block slab capacity
@@ -164,6 +172,14 @@ static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk)
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.selector_mtf, (size_t)cap * BZX_SEL_STRIDE))) return rc;
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.gbits, (size_t)cap * BZX_SEL_STRIDE))) return rc;
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.plist, (size_t)cap))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->slabs, &B.redo_list, (size_t)cap))) return rc;
+    if (ctx->use_bsort) {
+        if ((rc = dev_alloc(ctx, ctx->slabs, &B.pk, (size_t)cap * BZX_PK_STRIDE))) return rc;
+        if ((rc = dev_alloc(ctx, ctx->slabs, &B.rec_a, (size_t)cap * BZX_MAX_N))) return rc;
+        if ((rc = dev_alloc(ctx, ctx->slabs, &B.rec_b, (size_t)cap * BZX_MAX_N))) return rc;
+        if ((rc = dev_alloc(ctx, ctx->slabs, &B.bk_list, (size_t)cap * BZX_BK_PER_BLOCK))) return rc;
+        B.bk_cap = cap * BZX_BK_PER_BLOCK;
+    }
     if ((rc = dev_alloc(ctx, ctx->slabs, &ctx->d_outbuf, (size_t)cap * (BZX_OUT_STRIDE / 4)))) return rc;
     if (ctx->h_blk) (void)hipHostFree(ctx->h_blk);
     ctx->h_blk = nullptr;
@@ -211,6 +227,10 @@ extern "C" int bzx_ctx_create(int device, uint32_t max_blocks, bzx_ctx **out)
     memset(&ctx->B, 0, sizeof(ctx->B));
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     ctx->device = device;
+    {
+        const char *e = getenv("BZX_SORTER");
+        if (e && !strcmp(e, "general")) ctx->use_bsort = false;
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
         delete ctx;
@@ -230,13 +250,15 @@ extern "C" int bzx_ctx_create(int device, uint32_t max_blocks, bzx_ctx **out)
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreate(&ctx->ev_fork) != hipSuccess || hipEventCreate(&ctx->ev_join) != hipSuccess ||
-        hipEventCreate(&ctx->ev_bend) != hipSuccess) {
+        hipEventCreate(&ctx->ev_bend) != hipSuccess || hipEventCreate(&ctx->ev_b1) != hipSuccess ||
+        hipEventCreate(&ctx->ev_b2) != hipSuccess) {
         bzx_ctx_destroy(ctx);
         return BZX_E_HIP;
     }
     bool ok = hipMalloc((void **)&ctx->d_counters, 64 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&ctx->d_scalars, 8 * sizeof(uint64_t)) == hipSuccess &&
-              hipHostMalloc((void **)&ctx->h_scalars, 8 * sizeof(uint64_t), 0) == hipSuccess;
+              hipHostMalloc((void **)&ctx->h_scalars, 8 * sizeof(uint64_t), 0) == hipSuccess &&
+              hipHostMalloc((void **)&ctx->h_counters, 64 * sizeof(uint32_t), 0) == hipSuccess;
     if (!ok || ensure_blocks(ctx, max_blocks ? max_blocks : 16) != BZX_OK) {
         bzx_ctx_destroy(ctx);
         return BZX_E_NOMEM;
@@ -257,6 +279,9 @@ extern "C" void bzx_ctx_destroy(bzx_ctx *ctx)
     if (ctx->split_ws) (void)hipFree(ctx->split_ws);
     if (ctx->h_blk) (void)hipHostFree(ctx->h_blk);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->ev_b1) (void)hipEventDestroy(ctx->ev_b1);
+    if (ctx->ev_b2) (void)hipEventDestroy(ctx->ev_b2);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -308,7 +333,27 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
     B.ctr_mtf = 1;
     ctx->bwt_launches = 1;
     bool mtf_done = false;
-    if ((stages & STG_BWT) && nblk) {
+    ctx->bsort_used = false;
+    if ((stages & STG_BWT) && nblk && ctx->use_bsort) {
+        // bucket sorter: split every block into LDS-sized buckets, sort the buckets (any workgroup, any block), then
+        // the general sorter takes the blocks that were handed over (deep repeats, periodic blocks); usually none
+        const uint32_t ncu = (uint32_t)ctx->n_cu;
+        uint32_t per_cu = bzx_bwt_max_blocks_per_cu();
+        int rc = ensure_slots(ctx, ncu * per_cu);
+        if (rc) return rc;
+        const size_t items = (size_t)nblk * BZX_BK_PER_BLOCK < B.bk_cap ? (size_t)nblk * BZX_BK_PER_BLOCK : B.bk_cap;
+        HIP_TRY(ctx, hipMemsetAsync(B.bk_list, 0, items * sizeof(BzxBucket), ctx->stream));
+        bzx_launch_bsplit(B, nblk < ncu ? nblk : ncu, ctx->stream);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_b1, ctx->stream));
+        bzx_launch_bsort(B, bzx_bsort_blocks_per_cu() * ncu, ctx->stream);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_b2, ctx->stream));
+        ctx->bsort_used = true;
+        BzxBatch Br = B;
+        Br.redo = 1;
+        Br.ctr_bwt = BZX_CTR_REDO_FETCH;
+        bzx_launch_bwt(Br, grid_for(ctx, nblk, per_cu), ctx->stream);
+        bzx_launch_periodic(B, 16, ctx->stream);
+    } else if ((stages & STG_BWT) && nblk) {
         uint32_t per_cu = bzx_bwt_max_blocks_per_cu();
         uint32_t grid = grid_for(ctx, nblk, per_cu);
         int rc = ensure_slots(ctx, (uint32_t)ctx->n_cu * per_cu);
@@ -388,6 +433,7 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
     return BZX_OK;
 }
@@ -426,6 +472,16 @@ static void collect_stage_times(bzx_ctx *ctx)
     float ms[4] = {0, 0, 0, 0};
     for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]);
     ctx->stats.ms_bwt = ms[0];
+    ctx->stats.n_redo = 0;
+    ctx->stats.n_buckets = 0;
+    ctx->stats.ms_bwt_split = ctx->stats.ms_bwt_sort = ctx->stats.ms_bwt_general = 0.f;
+    if (ctx->bsort_used) {
+        ctx->stats.n_redo = ctx->h_counters[BZX_CTR_REDO];
+        ctx->stats.n_buckets = ctx->h_counters[BZX_CTR_BK_ITEMS];
+        (void)hipEventElapsedTime(&ctx->stats.ms_bwt_split, ctx->ev[0], ctx->ev_b1);
+        (void)hipEventElapsedTime(&ctx->stats.ms_bwt_sort, ctx->ev_b1, ctx->ev_b2);
+        (void)hipEventElapsedTime(&ctx->stats.ms_bwt_general, ctx->ev_b2, ctx->ev[1]);
+    }
     ctx->stats.bwt_launches = ctx->bwt_launches;
     ctx->stats.ms_mtf = ms[1];
     ctx->stats.ms_huffman = ms[2];
@@ -462,6 +518,7 @@ extern "C" int bzx_stage_bwt(bzx_ctx *ctx, const uint8_t *blk, size_t n, uint8_t
     return BZX_OK;
 }
 
+#ifdef BZX_DIAG
 // Debug/bench helper (not part of include/bzx.h): replicate one block `reps` times as a batch, run the
 // given stages, return the HIP-event time of each stage in ms[4] (bwt, mtf, huffman, emit).
 extern "C" int bzx_dbg_time_stages(bzx_ctx *ctx, const uint8_t *blk, size_t n, uint32_t reps, int stages, float ms[4])
@@ -488,6 +545,7 @@ extern "C" int bzx_dbg_time_stages(bzx_ctx *ctx, const uint8_t *blk, size_t n, u
     }
     return BZX_OK;
 }
+#endif   // BZX_DIAG
 
 extern "C" int bzx_stage_mtf(bzx_ctx *ctx, const uint8_t *bwt, size_t n, uint16_t *mtfv_out, uint32_t *n_mtf,
                              uint32_t freq_out[258], uint8_t in_use_out[256])
@@ -985,6 +1043,8 @@ extern "C" int bzx_shard_assemble_rank(bzx_ctx *ctx, const void *d_packed_r, uin
     return BZX_OK;
 }
 
+#ifdef BZX_DIAG
+// Diagnostic build only (libbzx_diag.so, -DBZX_DIAG; never in libbzx.so): phase timers of the sort kernels.
 // Debug helper (not in include/bzx.h): enable/read the BWT kernel's phase timers (100 MHz wall-clock ticks summed over blocks).
 extern "C" int bzx_dbg_set_stop(bzx_ctx *ctx, uint32_t k)
 {
@@ -993,17 +1053,17 @@ extern "C" int bzx_dbg_set_stop(bzx_ctx *ctx, uint32_t k)
     return BZX_OK;
 }
 
-extern "C" int bzx_dbg_phase_timers(bzx_ctx *ctx, int enable, unsigned long long out[64])
+extern "C" int bzx_dbg_phase_timers(bzx_ctx *ctx, int enable, unsigned long long out[128])
 {
     if (!ctx) return BZX_E_PARAM;
     if (enable && !ctx->d_dbg) {
-        if (hipMalloc((void **)&ctx->d_dbg, 64 * sizeof(unsigned long long)) != hipSuccess) return BZX_E_NOMEM;
+        if (hipMalloc((void **)&ctx->d_dbg, 128 * sizeof(unsigned long long)) != hipSuccess) return BZX_E_NOMEM;
     }
     if (out && ctx->d_dbg) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemcpy(out, ctx->d_dbg, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(out, ctx->d_dbg, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
-    if (ctx->d_dbg) HIP_TRY(ctx, hipMemset(ctx->d_dbg, 0, 64 * sizeof(unsigned long long)));
+    if (ctx->d_dbg) HIP_TRY(ctx, hipMemset(ctx->d_dbg, 0, 128 * sizeof(unsigned long long)));
     ctx->B.dbg = enable ? ctx->d_dbg : nullptr;
     return BZX_OK;
 }
@@ -1021,3 +1081,4 @@ extern "C" int bzx_dbg_block_times(bzx_ctx *ctx, uint32_t nblk, uint32_t *us_out
     }
     return BZX_OK;
 }
+#endif   // BZX_DIAG

@@ -1,0 +1,952 @@
+// bzx_bsort.hip -- bucket suffix sorter: the Burrows-Wheeler transform of bzip2 blocks, many workgroups per block.
+//
+// Contract (reference src/bwt_algorithms/bwt_sort.rs:27-58, bwt_encode): sort all cyclic rotations of the block,
+// L[j] = byte preceding the j-th smallest rotation, orig_ptr = row of rotation 0.
+//
+// Design (MI355X: 160 KB LDS per CU, 256 CUs): an MSD partition followed by sorts that never leave LDS.
+//   split kernel  (one workgroup per block): bytes in use -> dense ids -> packed block P (bzx_pack.h); histogram of
+//                 the first 15 bits of every rotation in LDS; adjacent bins are merged into BUCKETS of at most BS_C
+//                 rotations (bins above BS_C/3 stay alone); one pass writes a 64-bit record per rotation
+//                 [next 32 key bits | rotation:20 | preceding byte:8] into its bucket's range of ranks.  A bin that
+//                 alone exceeds BS_C is split again by its next 12 bits (records re-keyed from P), and so on.
+//   sort kernel   (work items = buckets, any workgroup takes any bucket of any block): the bucket's records are
+//                 loaded into LDS once and sorted there: stable 8-bit LSD passes over the 32 key bits, then
+//                 refinement rounds in which every rotation that is still tied fetches its next 50 key bits from P
+//                 (one 8-byte read; P of a block is shared by ~150 buckets and stays in L2) and each tied group is
+//                 ordered by them: groups of <= 64 by counting (each lane ranks its own record), up to 512 by one
+//                 wave (wave-level LSD passes, digits on which the group agrees are skipped), larger ones by the
+//                 whole workgroup.  L and orig_ptr are written when no ties are left.
+// HBM traffic per block: block read + P written/read + records written once and read once + L written: ~19 n.
+// Blocks that do not finish this way (a bucket still tied after BS_ROUNDS rounds: repeats of hundreds of symbols,
+// periodic blocks; or more split levels than BS_MAX_BIG tracks) are handed, whole, to the general sorter
+// (bzx_bwt.hip, prefix doubling) through B.redo_list; it also detects periodic blocks.
+#include <hip/hip_runtime.h>
+#include "bzx_device.h"
+#include "bzx_wg.h"
+#include "bzx_pack.h"
+
+#define BS_NT 1024                      // split kernel: lanes per workgroup
+#define BS_NW (BS_NT / 64)
+#ifndef BS_C
+#define BS_C 2048                       // rotations per bucket (records in LDS)
+#endif
+#define BS_FW (BS_C / 64)               // 64-bit words of group-start flags
+#define BS_ISO (BS_C / 3)               // bins above this stay alone
+#define BS_CP (BS_C - BS_ISO)           // merged bins must start inside one window of this many ranks
+#ifndef BS_BIN1
+#define BS_BIN1 15                      // bits of the level-1 bins
+#endif
+#define BS_BIN2 12                      // bits of the deeper levels
+#define BS_NBIN1 (1u << BS_BIN1)
+#define BS_TAB_WORDS (BS_NBIN1 + (BS_NBIN1 >> 5))
+#define BS_MAX_BK BZX_BK_PER_BLOCK      // buckets one split may produce
+#define BS_MAX_BIG 192                  // oversized bins waiting for a deeper split (per block)
+#define SP_U 4                          // split kernel: groups of four rotations in flight per lane
+#ifndef BS_ROUNDS
+#define BS_ROUNDS 32                    // refinement rounds of 50 bits before a bucket gives up (1600 bits)
+#endif
+#define BS_TINY 64                      // groups up to this size are ranked by counting
+#define BS_MED 512                      // ... up to this size by one wave
+#define REC_IDX(r) ((uint32_t)((r) >> 12) & 0xFFFFFu)
+#define REC_PREV(r) ((uint32_t)((r) >> 4) & 0xFFu)
+#define W_POS_MASK 0x3FFFull            // low 14 bits of a round word: position of the record in the bucket
+
+static_assert(BS_C <= 16384, "bucket capacity");
+
+// Phase timers and event counts, diagnostic build only (-DBZX_DIAG, libbzx_diag.so): B.dbg[128], 100 MHz ticks.
+#ifdef BZX_DIAG
+// accumulated per workgroup in LDS by lane 0 and flushed once at kernel exit (a global atomic per stamp made the
+// timers themselves the bottleneck once a launch had hundreds of thousands of buckets)
+__shared__ unsigned long long s_diag[128];
+#define DIAG_T0()                                                             \
+    unsigned long long t_last_ = 0;                                           \
+    if (B.dbg && threadIdx.x == 0) {                                          \
+        for (int i_ = 0; i_ < 128; i_++) s_diag[i_] = 0;                      \
+        t_last_ = wall_clock64();                                             \
+    }
+#define DIAG_STAMP(slot)                                                      \
+    do {                                                                      \
+        if (B.dbg && threadIdx.x == 0) {                                      \
+            const unsigned long long now_ = wall_clock64();                   \
+            s_diag[slot] += now_ - t_last_;                                   \
+            t_last_ = now_;                                                   \
+        }                                                                     \
+    } while (0)
+#define DIAG_COUNT(slot, v)                                                   \
+    do {                                                                      \
+        if (B.dbg && threadIdx.x == 0) s_diag[slot] += (unsigned long long)(v); \
+    } while (0)
+#define DIAG_FLUSH()                                                          \
+    do {                                                                      \
+        if (B.dbg && threadIdx.x == 0)                                        \
+            for (int i_ = 0; i_ < 128; i_++)                                  \
+                if (s_diag[i_]) atomicAdd(&B.dbg[i_], s_diag[i_]);            \
+    } while (0)
+#else
+#define DIAG_T0() do {} while (0)
+#define DIAG_STAMP(slot) do {} while (0)
+#define DIAG_COUNT(slot, v) do {} while (0)
+#define DIAG_FLUSH() do {} while (0)
+#endif
+
+// ------------------------------------------------------------------------------------------------ split kernel
+__shared__ uint32_t b_tab[BS_TAB_WORDS];     // bin counts, then bucket ids (index padded: b + b/32)
+__shared__ uint32_t b_start[BS_MAX_BK + 1];  // first rank of every bucket (relative to the range being split)
+__shared__ uint32_t b_first[BS_MAX_BK + 1];  // first bin of every bucket
+__shared__ uint32_t b_cur[BS_MAX_BK];        // scatter cursors
+__shared__ uint8_t b_b0[BS_MAX_BK];          // bits of the bin index that all bins of the bucket share
+__shared__ uint32_t b_inuse[256];
+__shared__ uint8_t b_seq[256];
+__shared__ uint32_t b_scratch[2 * BS_NW];
+__shared__ uint32_t b_bcast[8];              // [0] block, [1] big buckets, [2] item base, [3] big-list length
+__shared__ uint32_t b_big[BS_MAX_BIG][3];    // oversized bins: {start | buffer << 31, cnt, depth bits}
+
+#define TAB(b) b_tab[(b) + ((b) >> 5)]
+
+// Bins [0, BINS) counted in TAB -> buckets.  A new bucket starts at bin b when b or b-1 is above BS_ISO, or when
+// the bin's first rank lies in another BS_CP-window than its predecessor's: merged buckets stay below BS_C.
+// Returns the number of buckets (0: more than BS_MAX_BK); TAB(b) = bucket of bin b afterwards.
+template <int BINS>
+__device__ __forceinline__ uint32_t form_buckets(uint32_t total)
+{
+    constexpr int PER = BINS / BS_NT;
+    const uint32_t tid = threadIdx.x, bin0 = tid * PER;
+    uint32_t c[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        c[k] = TAB(bin0 + k);
+        sum += c[k];
+    }
+    const uint32_t prevc = tid ? TAB(bin0 - 1) : 0u;
+    uint32_t tot;
+    const uint32_t excl = bzx_block_excl_sum<BS_NT>(sum, b_scratch, tot);
+    uint32_t fl = 0, nf = 0;
+    {
+        uint32_t s = excl, ps = excl - prevc, pc = prevc;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const bool f = (bin0 + k == 0) || c[k] > BS_ISO || pc > BS_ISO || (s / BS_CP != ps / BS_CP);
+            fl |= (uint32_t)f << k;
+            nf += f;
+            ps = s;
+            s += c[k];
+            pc = c[k];
+        }
+    }
+    uint32_t nbk;
+    const uint32_t fexcl = bzx_block_excl_sum<BS_NT>(nf, b_scratch, nbk);
+    if (nbk > BS_MAX_BK) return 0;
+    {
+        uint32_t id = fexcl, s = excl;         // id = flags before this bin
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            if ((fl >> k) & 1u) {
+                b_start[id] = s;
+                b_first[id] = bin0 + k;
+                id++;
+            }
+            TAB(bin0 + k) = id - 1;
+            s += c[k];
+        }
+    }
+    if (tid == 0) {
+        b_start[nbk] = total;
+        b_first[nbk] = BINS;
+    }
+    __syncthreads();
+    return nbk;
+}
+
+// Bucket descriptors after form_buckets: shared bits, cursors.
+template <int BINW>
+__device__ __forceinline__ void bucket_setup(uint32_t nbk)
+{
+    for (uint32_t k = threadIdx.x; k < nbk; k += BS_NT) {
+        const uint32_t first = b_first[k], last = b_first[k + 1] - 1u;
+        b_b0[k] = (uint8_t)(first == last ? BINW : (uint32_t)__builtin_clz(first ^ last) - (32u - BINW));
+        b_cur[k] = 0;
+    }
+}
+
+// Work items for the buckets formed last: ranks base+b_start[k].. in buffer `buf`, keys from bit depth+b_b0[k].
+// Oversized buckets go to the big list instead (always a single bin: all its BINW bits are shared).
+// Returns false when the big list is full.
+template <int BINW>
+__device__ __forceinline__ bool bucket_emit(const BzxBatch &B, uint32_t blk, uint32_t nbk, uint32_t base, uint32_t buf,
+                                            uint32_t depth, uint32_t bits)
+{
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) b_bcast[2] = atomicAdd(&B.counters[BZX_CTR_BK_ITEMS], nbk);
+    __syncthreads();
+    const uint32_t ibase = b_bcast[2];
+    if (ibase + nbk > B.bk_cap) return false;      // work list full (the list is zeroed per batch: unwritten items are empty)
+    for (uint32_t k = tid; k < nbk; k += BS_NT) {
+        BzxBucket it;
+        it.blk = blk;
+        it.start = (base + b_start[k]) | (buf << 31);
+        it.cnt = b_start[k + 1] - b_start[k];
+        it.dbits = (depth + b_b0[k]) | (bits << 16);
+        if (it.cnt > BS_C) {
+            const uint32_t q = atomicAdd(&b_bcast[3], 1u);
+            if (q < BS_MAX_BIG) {
+                b_big[q][0] = it.start;
+                b_big[q][1] = it.cnt;
+                b_big[q][2] = depth + BINW;
+            }
+            it.cnt = 0;                          // the sort kernel skips empty items
+        }
+        B.bk_list[ibase + k] = it;
+    }
+    __syncthreads();
+    return b_bcast[3] <= BS_MAX_BIG;
+}
+
+__device__ __forceinline__ void block_redo(const BzxBatch &B, uint32_t b)
+{
+    if ((atomicOr(&B.blk[b].status, BZX_ST_REDO) & BZX_ST_REDO) == 0)
+        B.redo_list[atomicAdd(&B.counters[BZX_CTR_REDO], 1u)] = b;
+}
+
+__global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
+{
+    const uint32_t tid = threadIdx.x;
+    DIAG_T0();
+    for (;;) {
+        if (tid == 0) b_bcast[0] = atomicAdd(&B.counters[BZX_CTR_SPLIT_FETCH], 1u);
+        __syncthreads();
+        const uint32_t j_ = b_bcast[0];
+        __syncthreads();
+        if (j_ >= B.nblk) break;
+        const uint32_t b = B.blk_first + j_ * B.blk_step;
+        const uint32_t n = B.blk[b].n;
+        const uint8_t *__restrict__ T = BZX_BLOCK_PTR(B, B.blk[b]);
+        uint8_t *__restrict__ P = B.pk + (size_t)b * BZX_PK_STRIDE;
+        uint64_t *__restrict__ rec_a = B.rec_a + (size_t)b * BZX_MAX_N;
+        uint64_t *__restrict__ rec_b = B.rec_b + (size_t)b * BZX_MAX_N;
+
+        // ---- bytes in use -> dense symbol ids, bits per symbol, packed block
+        DIAG_STAMP(96);
+        if (tid < 256) b_inuse[tid] = 0;
+        if (tid == 0) {
+            b_bcast[1] = 0;
+            b_bcast[3] = 0;
+        }
+        __syncthreads();
+        {
+            const uint32_t n16 = n & ~15u;
+            for (uint32_t i = tid * 16; i < n16; i += BS_NT * 16) {
+                uint4 v;
+                __builtin_memcpy(&v, T + i, 16);          // unaligned: zero-copy blocks start anywhere in the raw input
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) b_inuse[(w[q] >> (8 * k)) & 255u] = 1;
+            }
+            for (uint32_t i = n16 + tid; i < n; i += BS_NT) b_inuse[T[i]] = 1;
+        }
+        __syncthreads();
+        uint32_t n_in_use;
+        {
+            const uint32_t flag = tid < 256 ? b_inuse[tid] : 0u;
+            const uint32_t ex = bzx_block_excl_sum<BS_NT>(flag, b_scratch, n_in_use);
+            if (tid < 256) b_seq[tid] = (uint8_t)ex;
+        }
+        __syncthreads();
+        uint32_t bits = 1;
+        while ((1u << bits) < n_in_use) bits++;
+        DIAG_STAMP(97);
+        pk_build_t<BS_NT>(T, n, bits, P, b_seq);
+        DIAG_STAMP(98);
+
+        // ---- level 1: histogram of the first BS_BIN1 bits of every rotation
+        for (uint32_t i = tid; i < BS_TAB_WORDS; i += BS_NT) b_tab[i] = 0;
+        __syncthreads();
+        for (uint32_t t0 = 0; t0 < n; t0 += BS_NT * 4 * SP_U) {
+            // four consecutive rotations per window of P (3*8+15 <= 57 bits), SP_U windows per lane in flight
+            uint64_t x[SP_U];
+#pragma unroll
+            for (uint32_t u = 0; u < SP_U; u++) {
+                const uint32_t i0 = t0 + (u * BS_NT + tid) * 4;
+                x[u] = i0 < n ? pk_window(P, i0, bits) : 0ull;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < SP_U; u++) {
+                const uint32_t i0 = t0 + (u * BS_NT + tid) * 4;
+#pragma unroll
+                for (uint32_t e = 0; e < 4; e++)
+                    if (i0 + e < n) atomicAdd(&TAB((uint32_t)((x[u] << (e * bits)) >> (64 - BS_BIN1))), 1u);
+            }
+        }
+        __syncthreads();
+        DIAG_STAMP(99);
+        uint32_t nbk = form_buckets<(int)BS_NBIN1>(n);
+        if (nbk) bucket_setup<BS_BIN1>(nbk);
+        __syncthreads();
+        DIAG_STAMP(100);
+        if (nbk == 0) {
+            DIAG_COUNT(106, 1);
+            if (tid == 0) block_redo(B, b);
+            __syncthreads();
+            continue;
+        }
+
+        // ---- level 1: one record per rotation into its bucket's range
+        for (uint32_t t0 = 0; t0 < n; t0 += BS_NT * 4 * SP_U) {
+            // the loads of SP_U groups of four rotations are issued before the first group is scattered
+            uint64_t hi[SP_U], lo[SP_U];
+            uint32_t pv[SP_U];                                            // bytes i0-1 .. i0+2 of the block
+#pragma unroll
+            for (uint32_t u = 0; u < SP_U; u++) {
+                const uint32_t i0 = t0 + (u * BS_NT + tid) * 4;
+                hi[u] = lo[u] = 0;
+                pv[u] = 0;
+                if (i0 < n) {
+                    uint64_t w2[2];
+                    __builtin_memcpy(w2, P + ((i0 * bits) >> 3), 16);     // 128-bit window: 64 valid bits for all four
+                    hi[u] = w2[0];
+                    lo[u] = w2[1];
+                    if (i0 >= 1 && i0 + 3 <= n) {
+                        __builtin_memcpy(&pv[u], T + i0 - 1, 4);
+                    } else {
+                        const uint32_t nvalid = n - i0 < 4u ? n - i0 : 4u;
+                        for (uint32_t e = 0; e < nvalid; e++) pv[u] |= (uint32_t)T[i0 + e ? i0 + e - 1 : n - 1] << (8 * e);
+                    }
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < SP_U; u++) {
+                const uint32_t i0 = t0 + (u * BS_NT + tid) * 4;
+                if (i0 < n) {
+                    const uint32_t nvalid = n - i0 < 4u ? n - i0 : 4u;
+                    const uint32_t sh0 = (i0 * bits) & 7u;
+                    const uint64_t h = __builtin_bswap64(hi[u]), l = __builtin_bswap64(lo[u]);
+#pragma unroll
+                    for (uint32_t e = 0; e < 4; e++) {
+                        if (e < nvalid) {
+                            const uint32_t sh = sh0 + e * bits;               // <= 31
+                            const uint64_t w = sh ? (h << sh) | (l >> (64u - sh)) : h;
+                            const uint32_t k = TAB((uint32_t)(w >> (64 - BS_BIN1)));
+                            const uint32_t key = (uint32_t)((w << b_b0[k]) >> 32);
+                            const uint32_t slot = atomicAdd(&b_cur[k], 1u);
+                            rec_a[b_start[k] + slot] = ((uint64_t)key << 32) | ((uint64_t)(i0 + e) << 12) |
+                                                       ((uint64_t)((pv[u] >> (8 * e)) & 255u) << 4);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        DIAG_STAMP(101);
+        bool ok = bucket_emit<BS_BIN1>(B, b, nbk, 0, 0, 0, bits);
+        DIAG_STAMP(102);
+
+        // ---- deeper levels: every oversized bin is split by its next BS_BIN2 bits into the other record buffer
+        // (its key field holds exactly those bits first); the records are re-keyed from P at the new depth
+        uint32_t done = 0;
+        while (ok) {
+            const uint32_t nbig = b_bcast[3];
+            __syncthreads();
+            if (done >= nbig) break;
+            const uint32_t st = b_big[done][0], cnt = b_big[done][1], depth = b_big[done][2];
+            done++;
+            const uint32_t base = st & 0x7fffffffu, buf = st >> 31;
+            const uint64_t *__restrict__ src = (buf ? rec_b : rec_a) + base;
+            uint64_t *__restrict__ dst = (buf ? rec_a : rec_b) + base;
+            if (depth + BS_BIN2 + 32 >= n * bits) {                   // a whole turn of the block is shared: general sorter
+                ok = false;
+                break;
+            }
+            constexpr uint32_t NB2 = 1u << BS_BIN2;
+            for (uint32_t i = tid; i < NB2 + (NB2 >> 5); i += BS_NT) b_tab[i] = 0;
+            if (tid == 0) b_bcast[1] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < cnt; i += BS_NT) atomicAdd(&TAB((uint32_t)(src[i] >> (64 - BS_BIN2))), 1u);
+            __syncthreads();
+            nbk = form_buckets<(int)NB2>(cnt);
+            if (nbk == 0) {
+                ok = false;
+                break;
+            }
+            bucket_setup<BS_BIN2>(nbk);
+            __syncthreads();
+            for (uint32_t i = tid; i < cnt; i += BS_NT) {
+                const uint64_t r = src[i];
+                const uint32_t k = TAB((uint32_t)(r >> (64 - BS_BIN2)));
+                uint32_t x = REC_IDX(r) * bits + depth + b_b0[k];           // bit offsets wrap at the block end
+                if (x >= n * bits) x -= n * bits;
+                const uint32_t key = (uint32_t)(pk_window_bit(P, x) >> 32);
+                const uint32_t slot = atomicAdd(&b_cur[k], 1u);
+                dst[b_start[k] + slot] = ((uint64_t)key << 32) | (r & 0xFFFFFFFFull);
+            }
+            __syncthreads();
+            ok = bucket_emit<BS_BIN2>(B, b, nbk, base, buf ^ 1u, depth, bits);
+            DIAG_COUNT(104, 1);
+            DIAG_COUNT(105, cnt);
+        }
+        DIAG_STAMP(103);
+        if (!ok) DIAG_COUNT(107, 1);
+        if (!ok && tid == 0) block_redo(B, b);
+        __syncthreads();
+    }
+    DIAG_FLUSH();
+}
+
+// -------------------------------------------------------------------------------------------------- sort kernel
+// 512-lane workgroups, BS_E records per lane, ~40 KB of LDS each: three or four of them share a compute unit, so the
+// LDS round trips and barriers of one overlap the work of the others (the kernel is latency-bound, not ALU-bound:
+// rocprofv3 SQ_WAIT_ANY was 72 % of the wave cycles with one dependent LDS round trip per row).
+#ifndef SK_NT
+#define SK_NT 256
+#endif
+#define SK_NW (SK_NT / 64)
+#define BS_E (BS_C / SK_NT)             // records per lane
+#define SK_DB 8                         // digit bits of the LDS radix passes
+#define SK_ND (1u << SK_DB)
+static_assert(BS_C % SK_NT == 0 && BS_E >= 1 && BS_E <= 8, "bucket capacity");
+
+__shared__ uint64_t s_x[BS_C];               // records, in rank order after the initial sort (never moved again)
+__shared__ uint64_t s_w[BS_C];               // rank p: [current 50 key bits | index into s_x of the record ranked p:14]
+__shared__ uint32_t s_cnt[SK_NW][SK_ND];     // per-wave digit counters
+__shared__ uint32_t s_dbase[SK_ND];
+__shared__ uint32_t s_part[4];
+__shared__ uint64_t s_f[BS_FW + 1];          // bit p: a group starts at rank p (all set from cnt on)
+__shared__ uint32_t s_med[BS_C / BS_TINY + 1];     // groups of 65..512: first rank | size << 16
+__shared__ uint32_t s_large[BS_C / BS_MED + 1];    // larger groups
+__shared__ uint32_t s_rc[2][4];              // per round (parity): [0] any rank tied, [1] #med, [2] #large, [3] med fetch
+__shared__ uint32_t s_bc[8];                 // [2] vote, [5..6] diff
+
+template <int WHICH> __device__ __forceinline__ uint64_t *lds_arr() { return WHICH ? s_w : s_x; }
+
+// Ordering point between LDS operations of ONE wave: the hardware executes a wave's LDS instructions in issue order
+// and all its lanes together, so only the compiler has to keep them in program order (no s_waitcnt is needed: a
+// fence would drain the LDS queue and a volatile access through a generic pointer becomes a FLAT load with a full
+// wait).  The CPU emulator runs lanes one after the other and needs a real rendezvous.
+#ifdef BZX_HIP_EMU
+#define lds_order() hipemu::wave_sync()
+#else
+#define lds_order() asm volatile("" ::: "memory")
+#endif
+
+// A value every lane of the workgroup loaded from the same address: keep it in a scalar register (values that are
+// live across the calls below would otherwise be spilled around every call: only 24 of 80 VGPRs are callee-saved).
+#ifdef BZX_HIP_EMU
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return v; }
+#else
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+#endif
+// The lane id, opaque to the optimiser: re-read at the top of a loop body it keeps address arithmetic derived from
+// it from being hoisted out of the loop, where dozens of such values would be spilled and reloaded from scratch
+// (global memory) inside the hot loops.
+__device__ __forceinline__ uint32_t tid_here()
+{
+    uint32_t t = threadIdx.x;
+#ifndef BZX_HIP_EMU
+    asm volatile("" : "+v"(t));
+#endif
+    return t;
+}
+__device__ __forceinline__ BzxBucket uni(BzxBucket b)
+{
+    BzxBucket r;
+    r.blk = uni(b.blk);
+    r.start = uni(b.start);
+    r.cnt = uni(b.cnt);
+    r.dbits = uni(b.dbits);
+    return r;
+}
+
+// Stable rank of digit d (valid lanes only) among everything this wave has counted in wc so far:
+// old = entries with digit d in earlier rows, rank = lanes below with the same digit in this row.
+// The lanes holding the same digit find each other with one ballot per digit bit (peers &= bit ? m : ~m, a single
+// 3-input v_bitop3 per half on gfx950); no LDS atomics on the per-element path: LDS atomics retire about one lane
+// per clock, which made OR-ing lane bits into LDS masks the bound of the whole kernel (measured).  Only the lowest
+// lane of each digit adds the row's count to the wave's counter, after every lane has read it (LDS executes a
+// wave's instructions in order, so nobody waits for the read before the add is issued).
+__device__ __forceinline__ void wave_rank(uint32_t *wc, uint32_t d, bool valid, uint32_t lane, uint32_t &old, uint32_t &rank)
+{
+    uint64_t m = __ballot(valid);
+    uint32_t plo = (uint32_t)m, phi = (uint32_t)(m >> 32);
+#pragma unroll
+    for (int b = 0; b < SK_DB; b++) {
+        const uint32_t mask = 0u - ((d >> b) & 1u);               // all ones where my bit is set
+        m = __ballot((d >> b) & 1u);
+        plo &= ~((uint32_t)m ^ mask);
+        phi &= ~((uint32_t)(m >> 32) ^ mask);
+    }
+    const uint64_t peers = ((uint64_t)phi << 32) | plo;
+    rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+    old = wc[d];
+    lds_order();
+    if (valid && rank == 0) atomicAdd(&wc[d], (uint32_t)__popcll(peers));
+    lds_order();
+}
+
+// Stable LSD sort (8-bit digits) of A[base .. base+cnt) (A = s_x or s_w) by bits [lo, hi) with the whole workgroup;
+// digits on which all agree are skipped.  Wave w owns the contiguous chunk [w*rows*64, (w+1)*rows*64), row j = 64
+// consecutive elements.  Starts and ends with workgroup barriers.
+template <int WHICH>
+__device__ __attribute__((noinline)) void wg_radix_sort(uint32_t base, uint32_t cnt, int lo, int hi)
+{
+    uint64_t *A = lds_arr<WHICH>() + base;
+    const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
+    const uint32_t rows = (cnt + SK_NT - 1) / SK_NT, chunk = rows * 64;
+    if (tid == 0) {
+        s_bc[5] = 0;
+        s_bc[6] = 0;
+    }
+    __syncthreads();
+    {
+        const uint64_t a0 = A[0];
+        uint64_t d = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t e = wave * chunk + j * 64 + lane;
+            if (j < rows && e < cnt) d |= A[e] ^ a0;
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) d |= __shfl_xor(d, s);
+        if (lane == 0 && d) {
+            atomicOr(&s_bc[5], (uint32_t)d);
+            atomicOr(&s_bc[6], (uint32_t)(d >> 32));
+        }
+    }
+    __syncthreads();
+    const uint64_t diff = ((uint64_t)s_bc[6] << 32) | s_bc[5];
+    uint32_t *wc = s_cnt[wave];
+    for (int shift = lo; shift < hi; shift += SK_DB) {
+        if (((diff >> shift) & (uint64_t)(SK_ND - 1)) == 0) continue;
+#pragma unroll
+        for (uint32_t i = 0; i < SK_ND / 64; i++) wc[i * 64 + lane] = 0;
+        lds_order();
+        uint64_t v[BS_E];
+        uint32_t old[BS_E], rk[BS_E];
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t e = wave * chunk + j * 64 + lane;
+            v[j] = j < rows && e < cnt ? A[e] : 0ull;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t e = wave * chunk + j * 64 + lane;
+            wave_rank(wc, (uint32_t)(v[j] >> shift) & (SK_ND - 1), j < rows && e < cnt, lane, old[j], rk[j]);
+        }
+        __syncthreads();
+        {
+            // exclusive start of every digit: SK_DK consecutive digits per thread, over waves first, then over digits
+            constexpr uint32_t SK_DK = SK_ND > SK_NT ? SK_ND / SK_NT : 1u;
+            if (tid * SK_DK < SK_ND) {
+                uint32_t tot[SK_DK], sum = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < SK_DK; i++) {
+                    uint32_t run = 0;
+#pragma unroll
+                    for (int w = 0; w < SK_NW; w++) {
+                        const uint32_t t = s_cnt[w][tid * SK_DK + i];
+                        s_cnt[w][tid * SK_DK + i] = run;
+                        run += t;
+                    }
+                    tot[i] = run;
+                    sum += run;
+                }
+                const uint32_t incl = bzx_wave_incl_sum(sum);
+                uint32_t run = incl - sum;
+#pragma unroll
+                for (uint32_t i = 0; i < SK_DK; i++) {
+                    s_dbase[tid * SK_DK + i] = run;
+                    run += tot[i];
+                }
+                if (lane == 63) s_part[wave] = incl;
+            }
+        }
+        __syncthreads();
+        const uint32_t p1 = s_part[0], p2 = p1 + s_part[1], p3 = p2 + s_part[2];
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t e = wave * chunk + j * 64 + lane;
+            if (j < rows && e < cnt) {
+                const uint32_t d = (uint32_t)(v[j] >> shift) & (SK_ND - 1);
+                const uint32_t q = SK_ND > SK_NT ? 0u : d >> 6;           // wave of the thread that scanned digit d
+                A[s_dbase[d] + (q == 0 ? 0u : q == 1 ? p1 : q == 2 ? p2 : p3) + wc[d] + old[j] + rk[j]] = v[j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// The same for s_w[base .. base+s), s <= BS_MED, by ONE wave (all 64 lanes call it together; no workgroup barriers).
+__device__ __attribute__((noinline)) void wave_radix_sort(uint32_t base, uint32_t s, int lo, int hi)
+{
+    constexpr uint32_t ROWS = BS_MED / 64;
+    uint64_t *A = s_w + base;
+    uint32_t *wc = s_cnt[bzx_wave()];
+    const uint32_t lane = bzx_lane();
+    const uint32_t rows = (s + 63u) / 64u;
+    uint64_t v[ROWS];
+    uint64_t diff = 0;
+    {
+        const uint64_t a0 = A[0];
+#pragma unroll
+        for (uint32_t j = 0; j < ROWS; j++) {
+            const uint32_t e = j * 64 + lane;
+            v[j] = e < s ? A[e] : 0ull;
+            if (e < s) diff |= v[j] ^ a0;
+        }
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) diff |= __shfl_xor(diff, sh);
+    }
+    for (int shift = lo; shift < hi; shift += SK_DB) {
+        if (((diff >> shift) & (uint64_t)(SK_ND - 1)) == 0) continue;
+#pragma unroll
+        for (uint32_t i = 0; i < SK_ND / 64; i++) wc[i * 64 + lane] = 0;
+        lds_order();
+        uint32_t old[ROWS], rk[ROWS];
+#pragma unroll
+        for (uint32_t j = 0; j < ROWS; j++) {
+            old[j] = rk[j] = 0;
+            if (j < rows) wave_rank(wc, (uint32_t)(v[j] >> shift) & (SK_ND - 1), j * 64 + lane < s, lane, old[j], rk[j]);
+        }
+        {
+            // exclusive scan of the SK_ND counts: SK_ND/64 digits per lane
+            uint32_t c[SK_ND / 64], sum = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < SK_ND / 64; i++) {
+                c[i] = wc[(SK_ND / 64) * lane + i];
+                sum += c[i];
+            }
+            uint32_t run = bzx_wave_incl_sum(sum) - sum;
+            lds_order();
+#pragma unroll
+            for (uint32_t i = 0; i < SK_ND / 64; i++) {
+                wc[(SK_ND / 64) * lane + i] = run;
+                run += c[i];
+            }
+        }
+        lds_order();
+#pragma unroll
+        for (uint32_t j = 0; j < ROWS; j++)
+            if (j * 64 + lane < s) A[wc[(uint32_t)(v[j] >> shift) & (SK_ND - 1)] + old[j] + rk[j]] = v[j];
+        lds_order();
+#pragma unroll
+        for (uint32_t j = 0; j < ROWS; j++) {
+            const uint32_t e = j * 64 + lane;
+            v[j] = e < s ? A[e] : 0ull;
+        }
+        lds_order();
+    }
+}
+
+__device__ __forceinline__ uint32_t fbit(uint32_t p) { return (uint32_t)(s_f[p >> 6] >> (p & 63u)) & 1u; }
+__device__ __forceinline__ void fset(uint32_t p) { atomicOr((unsigned long long *)&s_f[p >> 6], 1ull << (p & 63u)); }
+
+// Group [gs, ge) of rank p when it has at most BS_TINY members.
+__device__ __forceinline__ bool tiny_bounds(uint32_t p, uint32_t &gs, uint32_t &ge)
+{
+    const uint32_t wi = p >> 6, bi = p & 63u;
+    uint64_t w = s_f[wi] & (~0ull >> (63u - bi));
+    if (w) {
+        gs = wi * 64 + 63u - (uint32_t)__builtin_clzll(w);
+    } else {
+        if (wi == 0) return false;
+        w = s_f[wi - 1];
+        if (!w) return false;
+        gs = (wi - 1) * 64 + 63u - (uint32_t)__builtin_clzll(w);
+    }
+    w = bi == 63u ? 0ull : s_f[wi] & (~0ull << (bi + 1u));
+    if (w) {
+        ge = wi * 64 + (uint32_t)__builtin_ctzll(w);
+    } else {
+        w = s_f[wi + 1];
+        if (!w) return false;
+        ge = (wi + 1) * 64 + (uint32_t)__builtin_ctzll(w);
+    }
+    return ge - gs <= BS_TINY;
+}
+
+// After a sort of s_w[base .. base+s) by bits [lo, 64): a group starts wherever those bits change.  Lanes [t, t+step, ..).
+__device__ __forceinline__ void mark_changes(uint32_t base, uint32_t s, int lo, uint32_t t, uint32_t step)
+{
+    for (uint32_t e = 1 + t; e < s; e += step)
+        if ((s_w[base + e] >> lo) != (s_w[base + e - 1] >> lo)) fset(base + e);
+}
+
+// true when a member of s_w[base .. base+s) still sits in a group of more than BS_TINY ranks
+__device__ __forceinline__ bool any_big(uint32_t base, uint32_t s, uint32_t t, uint32_t step)
+{
+    bool big = false;
+    for (uint32_t e = t; e < s; e += step) {
+        uint32_t gs, ge;
+        big |= !tiny_bounds(base + e, gs, ge);
+    }
+    return big;
+}
+
+#ifndef SK_WAVES_PER_SIMD
+#define SK_WAVES_PER_SIMD 4             // 128 VGPRs: no spills (at 80 the round loop spills ~40 registers to scratch)
+#endif
+__global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(BzxBatch B)
+{
+    const uint32_t tid0 = threadIdx.x;
+    const uint32_t n_items = B.counters[BZX_CTR_BK_ITEMS] < B.bk_cap ? B.counters[BZX_CTR_BK_ITEMS] : B.bk_cap;
+    DIAG_T0();
+    // Work items are dealt round-robin (workgroup g sorts items g, g+G, ..: ~250 buckets each, so the load evens out
+    // without an atomic fetch on the critical path), which makes the NEXT item known early: its descriptor is loaded
+    // two iterations ahead and its records travel in registers while the current bucket is sorted.
+    const uint32_t G = gridDim.x;
+    uint32_t idx = blockIdx.x;
+    BzxBucket it = {0, 0, 0, 0}, nit = {0, 0, 0, 0};
+    if (idx < n_items) it = uni(B.bk_list[idx]);
+    if (idx + G < n_items) nit = uni(B.bk_list[idx + G]);
+    uint64_t nxt[BS_E];
+    uint32_t n_cur = 0, st_cur = 0;
+    if (it.cnt) {
+        const uint64_t *__restrict__ src = ((it.start >> 31) ? B.rec_b : B.rec_a) + (size_t)it.blk * BZX_MAX_N +
+                                           (it.start & 0x7fffffffu);
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) nxt[j] = j * SK_NT + tid0 < it.cnt ? src[j * SK_NT + tid0] : ~0ull;
+        n_cur = uni(B.blk[it.blk].n);
+        st_cur = uni(__atomic_load_n(&B.blk[it.blk].status, __ATOMIC_RELAXED));
+    }
+    for (; idx < n_items; idx += G) {
+        BzxBucket nit2 = {0, 0, 0, 0};
+        if (idx + 2 * G < n_items) nit2 = B.bk_list[idx + 2 * G];      // (made scalar when it becomes `nit`)
+        uint32_t tid = tid_here(), lane = tid & 63u, wave = tid >> 6;
+        const uint32_t b = it.blk, cnt = it.cnt;
+        const uint32_t start = it.start & 0x7fffffffu, bits = it.dbits >> 16, depth0 = it.dbits & 0xFFFFu;
+        const uint8_t *__restrict__ P = B.pk + (size_t)b * BZX_PK_STRIDE;
+        const uint32_t nbits = n_cur * bits;
+        const bool skip = cnt == 0 || (st_cur & BZX_ST_REDO);      // empty, or the block goes to the general sorter anyway
+        DIAG_STAMP(64);
+        if (!skip) {
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) s_x[j * SK_NT + tid] = nxt[j];
+        }
+        uint32_t n_nx = 0, st_nx = 0;
+        if (nit.cnt) {
+            const uint64_t *__restrict__ src = ((nit.start >> 31) ? B.rec_b : B.rec_a) + (size_t)nit.blk * BZX_MAX_N +
+                                               (nit.start & 0x7fffffffu);
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) nxt[j] = j * SK_NT + tid < nit.cnt ? src[j * SK_NT + tid] : ~0ull;
+            n_nx = B.blk[nit.blk].n;                                   // (made scalar when it becomes n_cur)
+            st_nx = __atomic_load_n(&B.blk[nit.blk].status, __ATOMIC_RELAXED);
+        }
+        if (skip) {
+            it = nit;
+            nit = uni(nit2);
+            n_cur = uni(n_nx);
+            st_cur = uni(st_nx);
+            continue;
+        }
+        if (tid == 0) s_rc[0][0] = s_rc[0][1] = s_rc[0][2] = s_rc[0][3] = 0;
+        DIAG_STAMP(65);
+        wg_radix_sort<0>(0, cnt, 32, 64);          // (its first barrier also publishes s_x)
+        DIAG_STAMP(66);
+        // rank p holds record p; group starts: the 32 key bits differ from the predecessor's
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t p = j * SK_NT + tid;
+            s_w[p] = p;
+            const bool f = p >= cnt || p == 0 || (uint32_t)(s_x[p] >> 32) != (uint32_t)(s_x[p - 1] >> 32);
+            const uint64_t m = __ballot(f);
+            if (lane == 0) s_f[j * SK_NW + wave] = m;
+        }
+        if (tid == 0) s_f[BS_FW] = ~0ull;
+        __syncthreads();
+        DIAG_STAMP(67);
+
+        uint32_t dcur = depth0 + 32;
+        bool fail = false;
+        for (uint32_t round = 0;; round++) {
+            tid = tid_here();
+            lane = tid & 63u;
+            wave = tid >> 6;
+            const uint32_t par = round & 1u;
+            const bool can = round < BS_ROUNDS && dcur < nbits;
+            // tied ranks fetch their next 50 key bits (bit offsets wrap at the block end): all gathers of a lane
+            // are issued together; groups above BS_TINY are listed while they are in flight
+            uint32_t tmask = 0, hmask = 0;                          // bit j: rank of row j is tied / heads its group
+            uint32_t xa[BS_E], pos[BS_E];
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) {
+                const uint32_t p = j * SK_NT + tid;
+                const uint32_t f0 = p < cnt ? fbit(p) : 1u, f1 = p < cnt ? fbit(p + 1) : 1u;
+                xa[j] = 0;
+                pos[j] = 0;
+                if (!(f0 && f1)) {
+                    tmask |= 1u << j;
+                    hmask |= f0 << j;
+                    pos[j] = (uint32_t)(s_w[p] & W_POS_MASK);
+                }
+            }
+            uint64_t g[BS_E];
+            if (can) {
+#pragma unroll
+                for (uint32_t j = 0; j < BS_E; j++) {
+                    if ((tmask >> j) & 1u) {
+                        uint32_t x = REC_IDX(s_x[pos[j]]) * bits + dcur;
+                        if (x >= nbits) x -= nbits;
+                        xa[j] = x;
+                    }
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < BS_E; j++) g[j] = ((tmask >> j) & 1u) ? pk_window_bit(P, xa[j]) : 0ull;
+#pragma unroll
+                for (uint32_t j = 0; j < BS_E; j++) {
+                    if ((hmask >> j) & 1u) {                                    // first rank of its group: measure it
+                        const uint32_t p = j * SK_NT + tid;
+                        uint32_t wi = p >> 6;
+                        uint64_t w = (s_f[wi] >> (p & 63u)) >> 1;               // flags after p
+                        uint32_t e;
+                        if (w) {
+                            e = p + 1u + (uint32_t)__builtin_ctzll(w);
+                        } else {
+                            do w = s_f[++wi]; while (!w);                       // ends at the sentinel word at the latest
+                            e = wi * 64 + (uint32_t)__builtin_ctzll(w);
+                        }
+                        const uint32_t size = e - p;
+                        if (size > BS_MED) s_large[atomicAdd(&s_rc[par][2], 1u)] = p | (size << 16);
+                        else if (size > BS_TINY) s_med[atomicAdd(&s_rc[par][1], 1u)] = p | (size << 16);
+                    }
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < BS_E; j++)
+                    if ((tmask >> j) & 1u) s_w[j * SK_NT + tid] = (g[j] & ~W_POS_MASK) | (uint64_t)pos[j];
+            }
+            if (tmask) s_rc[par][0] = 1;
+            if (tid == 0) s_rc[par ^ 1u][0] = s_rc[par ^ 1u][1] = s_rc[par ^ 1u][2] = s_rc[par ^ 1u][3] = 0;
+            __syncthreads();
+            DIAG_STAMP(68);
+            if (s_rc[par][0] == 0) break;
+            if (!can) {                                            // deep repeats / identical rotations: general sorter
+                DIAG_COUNT(round >= BS_ROUNDS ? 84 : 85, 1);
+                fail = true;
+                break;
+            }
+            DIAG_COUNT(80, 1);
+            const uint32_t nmed = s_rc[par][1], nlarge = s_rc[par][2];
+            if (nmed | nlarge) {
+                DIAG_COUNT(86, nmed);
+                DIAG_COUNT(87, nlarge);
+                // larger groups: sorted by the top 16 bits of their words only; the sub-groups that leaves are almost
+                // always small enough for the counting tier below, which compares whole words.  Otherwise: full sort.
+                for (;;) {
+                    uint32_t k = 0;
+                    if (lane == 0) k = atomicAdd(&s_rc[par][3], 1u);
+                    k = __shfl(k, 0);
+                    if (k >= nmed) break;
+                    const uint32_t e = s_med[k], gs = e & 0xFFFFu, sz = e >> 16;
+                    wave_radix_sort(gs, sz, 48, 64);
+                    mark_changes(gs, sz, 48, lane, 64);
+                    lds_order();
+                    if (__ballot(any_big(gs, sz, lane, 64))) {
+                        wave_radix_sort(gs, sz, 14, 64);
+                        mark_changes(gs, sz, 14, lane, 64);
+                    }
+                }
+                for (uint32_t k = 0; k < nlarge; k++) {
+                    const uint32_t e = s_large[k], gs = e & 0xFFFFu, sz = e >> 16;
+                    wg_radix_sort<1>(gs, sz, 48, 64);
+                    mark_changes(gs, sz, 48, tid, SK_NT);
+                    if (tid == 0) s_bc[2] = 0;
+                    __syncthreads();
+                    if (any_big(gs, sz, tid, SK_NT)) s_bc[2] = 1;
+                    __syncthreads();
+                    if (s_bc[2]) {
+                        wg_radix_sort<1>(gs, sz, 14, 64);
+                        mark_changes(gs, sz, 14, tid, SK_NT);
+                    }
+                }
+                __syncthreads();
+                DIAG_STAMP(69);
+            }
+            tid = tid_here();
+            lane = tid & 63u;
+            wave = tid >> 6;
+            // groups of up to BS_TINY ranks: every lane ranks its own word among its group's.  One row at a time, four
+            // members per step (four LDS reads in flight): a row costs as many steps as ITS largest group needs, and
+            // most rows hold only groups of a few ranks.
+            uint32_t dst_[BS_E];                                  // new rank | first-of-sub-group flag << 31; ~0: untouched
+            uint64_t my[BS_E];
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) {
+                dst_[j] = 0xFFFFFFFFu;
+                my[j] = 0;
+                uint32_t a_ = 0, sz = 0;
+                if ((tmask >> j) & 1u) {
+                    const uint32_t p = j * SK_NT + tid;
+                    uint32_t e_;
+                    if (tiny_bounds(p, a_, e_) && e_ - a_ > 1) {
+                        sz = e_ - a_;
+                        my[j] = s_w[p];
+                    }
+                }
+                uint32_t r = 0, eq = 0;
+                for (uint32_t i = 0; i < sz; i += 4) {
+                    uint64_t wq[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) wq[k] = s_w[a_ + (i + k < sz ? i + k : sz - 1)];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const bool lt = i + k < sz && wq[k] < my[j];
+                        r += lt;
+                        eq += lt && ((wq[k] ^ my[j]) >> 14) == 0;
+                    }
+                }
+                if (sz) dst_[j] = (a_ + r) | (eq ? 0u : 0x80000000u);
+            }
+            __syncthreads();
+            DIAG_STAMP(70);
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) {
+                if (dst_[j] != 0xFFFFFFFFu) {
+                    const uint32_t q = dst_[j] & 0x7FFFFFFFu;
+                    s_w[q] = my[j];
+                    if ((dst_[j] >> 31) && !fbit(q)) fset(q);      // first of its sub-group
+                }
+            }
+            __syncthreads();
+            DIAG_STAMP(71);
+            dcur += 50;
+        }
+        tid = tid_here();
+        if (fail) {
+            if (tid == 0) block_redo(B, b);
+        } else {
+            uint8_t *__restrict__ L = B.bwt + (size_t)b * BZX_BLK_STRIDE + start;
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) {
+                const uint32_t p = j * SK_NT + tid;
+                if (p < cnt) {
+                    const uint64_t r = s_x[(uint32_t)(s_w[p] & W_POS_MASK)];
+                    L[p] = (uint8_t)REC_PREV(r);
+                    if (REC_IDX(r) == 0) B.blk[b].orig_ptr = start + p;
+                }
+            }
+            DIAG_COUNT(83, 1);
+        }
+        __syncthreads();
+        DIAG_STAMP(72);
+        it = nit;
+        nit = uni(nit2);
+        n_cur = uni(n_nx);
+        st_cur = uni(st_nx);
+    }
+    DIAG_FLUSH();
+}
+
+void bzx_launch_bsplit(const BzxBatch &B, uint32_t grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_bsplit_kernel, dim3(grid), dim3(BS_NT), 0, stream, B);
+}
+
+void bzx_launch_bsort(const BzxBatch &B, uint32_t grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_bsort_kernel, dim3(grid), dim3(SK_NT), 0, stream, B);
+}
+
+uint32_t bzx_bsort_blocks_per_cu()
+{
+    int nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bzx_bsort_kernel, SK_NT, 0) != hipSuccess || nb < 1) nb = 1;
+    return (uint32_t)nb;
+}

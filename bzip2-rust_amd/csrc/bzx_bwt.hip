@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include "bzx_device.h"
 #include "bzx_wg.h"
+#include "bzx_pack.h"
 
 #define SORT_NT 1024
 #define SORT_NW (SORT_NT / 64)
@@ -90,74 +91,13 @@ __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t d, bool valid)
     }
 }
 
-// ---- the packed block --------------------------------------------------------------------------------------
-// Alphabet packing: the block's bytes are mapped to dense, order-preserving ids (s_seq) of `bits` bits each and
-// written once, most significant bit first, as one bit string P (symbol i at bit i*bits), continued cyclically
-// for PK_PAD symbols past the end.  Every key the sort needs is then ONE unaligned 8-byte read of P and a shift:
-// the 32-bit initial key is the first 32 bits of rotation i (32/bits whole symbols and the top of the next one:
-// fixed-width ids keep integer order == lexicographic order), a round key is the next csym symbols.
-#define PK_PAD 80u            // symbols of cyclic continuation: a 64-bit window at the last symbol stays inside P
+// ---- the packed block: see bzx_pack.h -----------------------------------------------------------------------
 #define PK_OFFSET 65536u      // P lives in the ISA array (unused in TEXT mode) behind the splitter's scratch lists
 
-// >= 57 valid bits of rotation pos, most significant first
-__device__ __forceinline__ uint64_t pk_window(const uint8_t *__restrict__ P, uint32_t pos, uint32_t bits)
-{
-    const uint32_t b = pos * bits;
-    uint64_t w;
-    __builtin_memcpy(&w, P + (b >> 3), 8);      // unaligned 8-byte global load
-    return __builtin_bswap64(w) << (b & 7u);
-}
-
-// Builds P from the block: one lane per 64 symbols = `bits` whole 8-byte words (big-endian bit order).
 __device__ __attribute__((noinline)) void pk_build(const uint8_t *__restrict__ T, uint32_t n, uint32_t bits,
                                                    uint8_t *__restrict__ P)
 {
-    const uint32_t ngroups = (n + PK_PAD + 63u) / 64u + 1u;       // one group of zeros behind the continuation
-    for (uint32_t q = threadIdx.x; q < ngroups; q += SORT_NT) {
-        const uint32_t pos = 64u * q;
-        uint32_t c[16];                                            // 64 block bytes, cyclic
-        if (pos + 64u <= n) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint4 v;
-                __builtin_memcpy(&v, T + pos + 16 * k, 16);
-                c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) c[k] = 0;
-            if (pos < n + PK_PAD) {
-                uint32_t pm = pos % n;
-                for (int j = 0; j < 64; j++) {
-                    c[j >> 2] |= (uint32_t)T[pm] << (8 * (j & 3));
-                    pm = pm + 1 == n ? 0u : pm + 1;
-                }
-            }
-        }
-        uint64_t *out = reinterpret_cast<uint64_t *>(P) + (size_t)q * bits;      // P is 8-byte aligned
-        uint64_t acc = 0;
-        uint32_t have = 0;                                         // bits in acc
-        const bool real = pos < n + PK_PAD;
-#pragma unroll
-        for (int j = 0; j < 64; j++) {
-            const uint64_t id = real ? s_seq[(c[j >> 2] >> (8 * (j & 3))) & 255u] : 0u;
-            if (have + bits <= 64u) {
-                acc = bits == 64u ? id : (acc << bits) | id;
-                have += bits;
-            } else {                                               // the symbol straddles a word boundary
-                const uint32_t hi = 64u - have, lo = bits - hi;
-                *out++ = __builtin_bswap64((acc << hi) | (id >> lo));
-                acc = id & ((1ull << lo) - 1ull);
-                have = lo;
-            }
-            if (have == 64u) {
-                *out++ = __builtin_bswap64(acc);
-                acc = 0;
-                have = 0;
-            }
-        }
-    }
-    __syncthreads();
+    pk_build_t<SORT_NT>(T, n, bits, P, s_seq);
 }
 
 // INIT record of rotation i: [first 32 bits of the packed rotation @28 | i:20 @8 | preceding byte:8 @0]
@@ -1004,6 +944,7 @@ __device__ __attribute__((noinline)) uint32_t big_split(uint64_t *__restrict__ U
 }
 
 // diagnostic phase timers (B.dbg != null only in profiling runs): accumulate wall-clock ticks per phase
+#ifdef BZX_DIAG
 #define PHASE_STAMP(slot)                                                     \
     do {                                                                      \
         if (B.dbg && tid == 0) {                                              \
@@ -1012,6 +953,15 @@ __device__ __attribute__((noinline)) uint32_t big_split(uint64_t *__restrict__ U
             t_last = now_;                                                    \
         }                                                                     \
     } while (0)
+#define DBG_STOP(k) (B.dbg_stop == (k))
+#define DBG_ON (B.dbg != nullptr)
+#define DBG_STOP_ANY (B.dbg_stop != 0)
+#else
+#define PHASE_STAMP(slot) do {} while (0)
+#define DBG_STOP(k) false
+#define DBG_ON false
+#define DBG_STOP_ANY false
+#endif
 
 __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
 {
@@ -1024,14 +974,14 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         __syncthreads();
         const uint32_t j_ = s_bcast[0];
         __syncthreads();
-        if (j_ >= B.nblk) break;
-        const uint32_t b = B.blk_first + j_ * B.blk_step;
+        if (j_ >= (B.redo ? B.counters[BZX_CTR_REDO] : B.nblk)) break;
+        const uint32_t b = B.redo ? B.redo_list[j_] : B.blk_first + j_ * B.blk_step;
 
         const uint32_t n = B.blk[b].n;
         const uint8_t *__restrict__ T = BZX_BLOCK_PTR(B, B.blk[b]);
         uint8_t *__restrict__ L = B.bwt + (size_t)b * BZX_BLK_STRIDE;
         unsigned long long t_blk0 = 0;
-        if (B.dbg && tid == 0) t_last = t_blk0 = wall_clock64();
+        if (DBG_ON && tid == 0) t_last = t_blk0 = wall_clock64();
 
         // ---- A: bytes in use -> dense symbol ids; symbols per key
         if (tid < 256) s_inuse[tid] = 0;
@@ -1097,7 +1047,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         }
         __syncthreads();
         PHASE_STAMP(0);
-        if (B.dbg_stop == 1) continue;
+        if (DBG_STOP(1)) continue;
 
         // ---- I2: four LSD passes over the 32-bit key (record bits 28..59)
         radix_pass<SRC_TEXT>(nullptr, ws.u0, n, TXT_KEY_SHIFT, s_hist[0], T, bits, P);
@@ -1105,7 +1055,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         radix_pass<SRC_REC>(ws.u1, ws.u0, n, TXT_KEY_SHIFT + 16, s_hist[2]);
         radix_pass<SRC_REC>(ws.u0, ws.u1, n, TXT_KEY_SHIFT + 24, s_hist[3]);
         PHASE_STAMP(1);
-        if (B.dbg_stop == 2) continue;
+        if (DBG_STOP(2)) continue;
 
         // ---- R: ranks by the first four bytes
         uint64_t *ua = ws.u0, *ub = ws.u1;      // ua: current compacted records, ub: the other buffer
@@ -1113,7 +1063,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         uint32_t *orig_out = &B.blk[b].orig_ptr;
         uint32_t m = rerank<MODE_INIT>(ws.u1, nullptr, n, ua, sa_cur, ws.isa, ws.sa, L, orig_out, T, n);
         PHASE_STAMP(2);
-        if (B.dbg_stop == 3) continue;
+        if (DBG_STOP(3)) continue;
 
         // ---- TEXT rounds: csym more symbols per round; oversized groups are split by single symbols first
         uint32_t depth = ksym, round = 0, frozen_depth = 0xffffffffu;
@@ -1125,10 +1075,10 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
                 PHASE_STAMP(10 + (round < 7 ? round : 7) * 3);
                 if (fr && fr < frozen_depth) frozen_depth = fr;           // frozen groups agree on >= fr symbols
             }
-            if (B.dbg_stop == 4) break;
+            if (DBG_STOP(4)) break;
             seg_sort_round<true, 4>(ua, m, nullptr, P, n, depth, bits, csym);
             PHASE_STAMP(8 + (round < 7 ? round : 7) * 3);
-            if (B.dbg_stop == 5) break;
+            if (DBG_STOP(5)) break;
             const uint32_t m_before = m;
             m = rerank<MODE_TEXT>(ua, sa_cur, m, ub, sa_alt, ws.isa, ws.sa, L, orig_out, T, n);
             PHASE_STAMP(9 + (round < 7 ? round : 7) * 3);
@@ -1136,13 +1086,13 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
             uint32_t *ts = sa_cur; sa_cur = sa_alt; sa_alt = ts;
             depth += csym;
             round++;
-            if (B.dbg_stop == 6) break;
+            if (DBG_STOP(6)) break;
             // long repeats: when a round resolves less than 30 % of what it was given, doubling is cheaper
             if (round >= 2 && (uint64_t)m * 10 > (uint64_t)m_before * 7) break;
             if ((uint64_t)m * 10 > (uint64_t)m_before * 9) break;      // (almost) nothing but deep repeats / frozen groups left
         }
         __syncthreads();
-        if (B.dbg_stop) continue;
+        if (DBG_STOP_ANY) continue;
 
         // ---- RANK rounds (deep repeats): build ISA once, then prefix doubling on ranks
         if (m > 0 && depth < n) {
@@ -1163,7 +1113,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
                 const uint32_t maxgrp = unmeasured ? 0xFFFFFu : s_bcast[3];
                 unmeasured = false;
                 __syncthreads();
-                if (B.dbg && tid == 0) {       // diagnostics: unresolved rotations / largest group entering RANK round r
+                if (DBG_ON && tid == 0) {       // diagnostics: unresolved rotations / largest group entering RANK round r
                     atomicAdd(&B.dbg[52 + (rround < 5 ? rround : 5) * 2], (unsigned long long)m);
                     atomicAdd(&B.dbg[53 + (rround < 5 ? rround : 5) * 2], (unsigned long long)maxgrp);
                 }
@@ -1192,7 +1142,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
             PHASE_STAMP(4);
         }
         PHASE_STAMP(3);
-        if (B.dbg && tid == 0) B.blk[b].pad_[1] = (uint32_t)((wall_clock64() - t_blk0) / 100);   // microseconds in this kernel
+        if (DBG_ON && tid == 0) B.blk[b].pad_[1] = (uint32_t)((wall_clock64() - t_blk0) / 100);   // microseconds in this kernel
         if (tid == 0) {
             B.blk[b].status = (m > 0) ? BZX_ST_PERIODIC : 0u;
             if (m > 0) {

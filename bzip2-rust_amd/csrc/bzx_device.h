@@ -19,6 +19,29 @@
 
 #define BZX_IN_RAW (1ull << 63)
 #define BZX_ST_PERIODIC 1u         // block is u^k, k>1: identical rotations exist
+#define BZX_ST_REDO 2u             // the bucket sorter handed the block to the general sorter (deep repeats)
+#define BZX_PK_STRIDE 900352u      // per-block stride of the packed blocks (bzx_pack.h): (n + 207 symbols) * 8 bits max
+#ifndef BZX_BK_PER_BLOCK
+#define BZX_BK_PER_BLOCK 1024u     // bucket work items reserved per block
+#endif
+
+// counters[] slots (BzxBatch.counters, zeroed per batch)
+#define BZX_CTR_PERIODIC 5         // blocks flagged periodic
+#define BZX_CTR_BK_ITEMS 8         // bucket work items produced by the split kernel
+#define BZX_CTR_BK_FETCH 9         // ... fetched by the bucket sort kernel
+#define BZX_CTR_REDO 10            // blocks handed to the general sorter
+#define BZX_CTR_SPLIT_FETCH 11     // blocks fetched by the split kernel
+#define BZX_CTR_REDO_FETCH 12      // blocks fetched by the general sorter in redo mode
+#define BZX_CTR_STAT0 16           // [16..31] diagnostics of the bucket sorter (rounds, leftovers, ...)
+
+// One bucket of rotations: ranks [start, start+cnt) of block blk, all sharing the first `dbits` bits; records
+// [next 32 key bits:32 | rotation:20 | preceding byte:8 | 0:4] at rec{A,B}[blk * BZX_MAX_N + start ..].
+struct BzxBucket {
+    uint32_t blk;
+    uint32_t start;         // bit 31: records live in recB
+    uint32_t cnt;
+    uint32_t dbits;         // low 16: key depth in bits; bits 16..19: bits per symbol of the block
+};
 
 // Per-block descriptor, device resident; filled by the splitter (or the host for the
 // per-block entry points), completed by each stage.
@@ -75,6 +98,13 @@ struct BzxBatch {
     uint16_t *gbits;        // [nblk][BZX_SEL_STRIDE]  payload bits of every 50-symbol group
     uint32_t *out;          // output bit buffer (zeroed), big-endian bit order
     BzxSortWs *sort_ws;     // [n_slots]
+    uint8_t *pk;            // [nblk][BZX_PK_STRIDE]   packed blocks (bucket sorter)
+    uint64_t *rec_a;        // [nblk][BZX_MAX_N]       bucket records
+    uint64_t *rec_b;        // [nblk][BZX_MAX_N]       ... of the deeper split levels
+    BzxBucket *bk_list;     // [bk_cap] bucket work items (zeroed per batch)
+    uint32_t bk_cap;
+    uint32_t *redo_list;    // [nblk] blocks for the general sorter
+    uint32_t redo;          // general sorter: take the blocks from redo_list (count = counters[BZX_CTR_REDO])
     uint32_t n_slots;
     uint32_t dbg_stop;       // diagnostics only: leave the BWT kernel after phase k (0 = run everything)
     unsigned long long *dbg; // optional [64] phase timers (100 MHz ticks), null in production

@@ -142,7 +142,9 @@ typedef struct {
     float ms_split, ms_bwt, ms_mtf, ms_huffman, ms_emit, ms_total;   /* HIP-event times of the stage kernels */
     uint32_t bwt_launches;      /* launches of the BWT kernel in the last run (2 when its partial last round
                                    ran beside the MTF stage on a second stream); ms_bwt covers all of them */
-    uint32_t reserved_;
+    uint32_t n_redo;            /* blocks the bucket sorter handed to the general sorter (deep repeats, periodic) */
+    uint32_t n_buckets;         /* bucket work items of the bucket sorter */
+    float ms_bwt_split, ms_bwt_sort, ms_bwt_general;   /* parts of ms_bwt: split kernel, bucket sort kernel, general sorter + periodic */
 } bzx_stats;
 int bzx_get_stats(const bzx_ctx *ctx, bzx_stats *out);
 

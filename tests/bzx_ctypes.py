@@ -19,7 +19,8 @@ class BzxStats(C.Structure):
                 ("rle1_bytes", C.c_uint64), ("mtf_symbols", C.c_uint64), ("out_bits", C.c_uint64),
                 ("ms_split", C.c_float), ("ms_bwt", C.c_float), ("ms_mtf", C.c_float),
                 ("ms_huffman", C.c_float), ("ms_emit", C.c_float), ("ms_total", C.c_float),
-                ("bwt_launches", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("bwt_launches", C.c_uint32), ("n_redo", C.c_uint32), ("n_buckets", C.c_uint32),
+                ("ms_bwt_split", C.c_float), ("ms_bwt_sort", C.c_float), ("ms_bwt_general", C.c_float)]
 
 
 class BzxError(RuntimeError):
@@ -242,6 +243,20 @@ class Oracle:
         b = C.create_string_buffer(n)
         self.lib.bzo_xorshift_bytes(seed, b, n)
         return b.raw[:n]
+
+    def compress_mt(self, data: bytes, level=9, threads=None):
+        """Same stream as compress(), one block per worker thread (oracle_driver.c; compress.rs:125-132)."""
+        L = self.lib
+        L.bzo_compress_buffer_mt.restype = C.c_size_t
+        L.bzo_compress_buffer_mt.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t,
+                                             C.POINTER(C.c_int32)]
+        cap = len(data) + len(data) // 50 + 4096
+        out = C.create_string_buffer(cap)
+        nb = C.c_int32()
+        n = L.bzo_compress_buffer_mt(data, len(data), level, threads or min(16, os.cpu_count() or 1), out, cap, C.byref(nb))
+        if n == 0 and len(data):
+            raise RuntimeError("oracle compress_mt overflow")
+        return out.raw[:n]
 
     def compress(self, data: bytes, level=9):
         cap = len(data) + len(data) // 50 + 4096

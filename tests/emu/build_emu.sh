@@ -5,6 +5,6 @@ cd "$(dirname "$0")/../.."
 SRCS=$(ls bzip2-rust_amd/csrc/*.hip)
 ARGS=""
 for s in $SRCS; do ARGS="$ARGS -x c++ $s"; done
-g++ -O1 -g -std=c++17 -fPIC -shared -w -DSCAN_SEG=16 -I tests/emu $ARGS -x c++ tests/emu/hip_emu.cpp \
+g++ -O1 -g -std=c++17 -fPIC -shared -w -DSCAN_SEG=16 -DBS_C=2048 -I tests/emu $ARGS -x c++ tests/emu/hip_emu.cpp \
     -Wl,--unresolved-symbols=ignore-all -o tests/emu/libbzx_emu.so
 echo built tests/emu/libbzx_emu.so
