@@ -25,7 +25,7 @@ void bzx_launch_mtf(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_huffman(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_emit(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_layout(const BzxBatch &B, uint64_t first_bit, uint64_t stride_bits, uint64_t *d_total_bits,
-                       hipStream_t stream);
+                       hipStream_t stream, uint64_t *d_phase = nullptr);
 void bzx_launch_stream_frame(const BzxBatch &B, int level, const uint64_t *d_total_bits, uint64_t *d_out_bytes,
                              hipStream_t stream);
 int bzx_split_launch_boundaries(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t max_blocks,
@@ -98,6 +98,9 @@ struct bzx_ctx {
     uint32_t shard_total = 0, shard_rank = 0, shard_world = 1;
     int shard_level = 0;
     size_t shard_len = 0;
+
+    struct bzx_cstream *cs = nullptr;        // chunked stream compressor kept for bzx_compress_buffer
+    std::vector<uint8_t> split_carry;        // bzx_split_rle1_chunk: raw bytes of the withheld block
 
     // device split scratch (bzx_rle1.hip)
     void *split_ws = nullptr;
@@ -267,10 +270,16 @@ extern "C" int bzx_ctx_create(int device, uint32_t max_blocks, bzx_ctx **out)
     return BZX_OK;
 }
 
+extern "C" void bzx_cstream_end(struct bzx_cstream *s);
+
 extern "C" void bzx_ctx_destroy(bzx_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->cs) {
+        bzx_cstream_end(ctx->cs);
+        ctx->cs = nullptr;
+    }
     (void)hipStreamSynchronize(ctx->stream);
     free_all(ctx->slabs);
     free_all(ctx->slot_allocs);
@@ -320,8 +329,11 @@ enum { STG_BWT = 1, STG_MTF = 2, STG_HUF = 4, STG_EMIT = 8, STG_ALL = 15 };
 // Runs the stage kernels over blocks [0,nblk) whose descriptors (in_off,n,crc) are already on the device.
 // STG_EMIT: out_level == 0 -> every block image byte-aligned in its own slab of ctx->d_outbuf;
 //           out_level 1..9 -> one .bz2 stream in d_stream_out (cap bytes, device memory).
+//           out_level -1   -> one CHUNK of a stream (bzx_cstream_*): the block images back to back in d_stream_out,
+//                             starting at the bit phase d_phase[0] (kept on the device from chunk to chunk); no header,
+//                             no footer, no host synchronisation
 static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0, void *d_stream_out = nullptr,
-                      size_t stream_cap = 0)
+                      size_t stream_cap = 0, uint64_t *d_phase = nullptr)
 {
     BzxBatch &B = ctx->B;
     B.nblk = nblk;
@@ -408,7 +420,12 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
     if ((stages & STG_HUF) && nblk) bzx_launch_huffman(B, grid_for(ctx, nblk, 3), ctx->stream);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     if (stages & STG_EMIT) {
-        if (out_level == 0) {
+        if (out_level < 0) {
+            B.out = (uint32_t *)d_stream_out;
+            bzx_launch_layout(B, 0, 0, ctx->d_scalars, ctx->stream, d_phase);
+            HIP_TRY(ctx, hipMemsetAsync(d_stream_out, 0, stream_cap, ctx->stream));
+            if (nblk) bzx_launch_emit(B, grid_for(ctx, nblk, 2), ctx->stream);
+        } else if (out_level == 0) {
             B.out = ctx->d_outbuf;
             bzx_launch_layout(B, 0, (uint64_t)BZX_OUT_STRIDE * 8, ctx->d_scalars, ctx->stream);
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_outbuf, 0, (size_t)nblk * BZX_OUT_STRIDE, ctx->stream));
@@ -745,7 +762,7 @@ static int level_ok(int level) { return level >= 1 && level <= 9; }
 
 // Device split: raw (device) -> block slabs + descriptors (n, crc, in_off).  Returns the block count.
 static int split_on_device(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t *nblk_out,
-                           uint32_t own_first = 0, uint32_t own_step = 1)
+                           uint32_t own_first = 0, uint32_t own_step = 1, uint64_t *last_raw_start = nullptr)
 {
     *nblk_out = 0;
     if (len == 0) return BZX_OK;
@@ -764,6 +781,14 @@ static int split_on_device(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int l
     if (nblk == 0 || nblk > max_blocks) {
         ctx->err = "device block splitter produced an impossible block count";
         return BZX_E_HIP;
+    }
+    if (last_raw_start) {
+        // raw position where the last block starts: a chunked caller restarts the split there (the splitter's state
+        // is clean at a block start: a block is a whole number of run pieces, bzx_rle1.hip)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scalars + 5, ws.blk_raw + (nblk - 1), sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        *last_raw_start = ctx->h_scalars[5];
     }
     bzx_split_launch_scatter(ctx, d_raw, len, ws, nblk, ctx->d_in, ctx->B.blk, own_first, own_step);
     HIP_TRY(ctx, hipGetLastError());
@@ -816,32 +841,55 @@ extern "C" int bzx_compress_device(bzx_ctx *ctx, const void *d_raw, size_t len, 
     return BZX_OK;
 }
 
+extern "C" int bzx_cstream_begin(bzx_ctx *ctx, int level, size_t max_chunk, struct bzx_cstream **out);
+extern "C" int bzx_cstream_feed(struct bzx_cstream *s, const uint8_t *raw, size_t len, int final, uint8_t *out, size_t cap,
+                                size_t *produced);
+extern "C" void bzx_cstream_end(struct bzx_cstream *s);
+static int cstream_reset(struct bzx_cstream *s, int level);
+static size_t cstream_chunk_of(const struct bzx_cstream *s);
+static size_t cstream_need_hint(const struct bzx_cstream *s);
+
+// Host buffer -> host buffer: the chunked stream compressor over the whole input (H2D of chunk k+1, compression of
+// chunk k and D2H of chunk k-1 overlap; no device allocation per call: the stream object is kept in the context).
+// Pinned caller buffers (hipHostMalloc / hipHostRegister / bzx_host_alloc) make the copies truly asynchronous.
 extern "C" int bzx_compress_buffer(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level, uint8_t *out, size_t cap,
                                    size_t *out_len)
 {
     std::unique_lock<std::recursive_mutex> api_lock_;
     if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
-    if (!ctx || !out || !out_len || !level_ok(level) || (len && !raw)) return BZX_E_PARAM;
+    if (!ctx || !out || !out_len || !level_ok(level) || (len && !raw) || cap < 16) return BZX_E_PARAM;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    void *d_raw = nullptr, *d_out = nullptr;
-    const size_t dcap = len + len / 4 + 8192;   // worst case: every block expands by 1% + 600 after RLE1's 25%
-    if (hipMalloc(&d_raw, len ? len : 16) != hipSuccess) return BZX_E_NOMEM;
-    if (hipMalloc(&d_out, dcap) != hipSuccess) {
-        (void)hipFree(d_raw);
-        return BZX_E_NOMEM;
+    size_t chunk = (size_t)16 << 20;
+    while (chunk < len && chunk < ((size_t)256 << 20)) chunk <<= 1;
+    int rc;
+    if (ctx->cs && cstream_chunk_of(ctx->cs) < chunk) {
+        bzx_cstream_end(ctx->cs);
+        ctx->cs = nullptr;
     }
-    int rc = BZX_OK;
-    size_t ol = 0;
-    if (len && hipMemcpyAsync(d_raw, raw, len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = BZX_E_HIP;
-    if (!rc) rc = bzx_compress_device(ctx, d_raw, len, level, d_out, dcap, &ol);
-    if (!rc) {
-        *out_len = ol;
-        if (ol > cap) rc = BZX_E_OUTBUF;
-        else if (hipMemcpy(out, d_out, ol, hipMemcpyDeviceToHost) != hipSuccess) rc = BZX_E_HIP;
+    if (!ctx->cs) {
+        if ((rc = bzx_cstream_begin(ctx, level, chunk, &ctx->cs))) return rc;
+    } else if ((rc = cstream_reset(ctx->cs, level))) {
+        return rc;
     }
-    (void)hipFree(d_raw);
-    (void)hipFree(d_out);
-    return rc;
+    chunk = cstream_chunk_of(ctx->cs);
+    hipEvent_t e0 = ctx->ev[5], e1 = ctx->ev[7];
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    size_t off = 0, produced = 0;
+    do {
+        const size_t n = len - off < chunk ? len - off : chunk;
+        const int fin = off + n == len;
+        if ((rc = bzx_cstream_feed(ctx->cs, raw + off, n, fin, out, cap, &produced))) {
+            if (rc == BZX_E_OUTBUF) *out_len = cstream_need_hint(ctx->cs);      // (a lower bound when chunks remain)
+            return rc;
+        }
+        off += n;
+    } while (off < len);
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(e1));
+    (void)hipEventElapsedTime(&ctx->stats.ms_total, e0, e1);
+    ctx->stats.raw_bytes = len;
+    *out_len = produced;
+    return BZX_OK;
 }
 
 extern "C" int bzx_split_rle1(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level, uint8_t *blocks_out,
@@ -1040,6 +1088,361 @@ extern "C" int bzx_shard_assemble_rank(bzx_ctx *ctx, const void *d_packed_r, uin
     bzx_launch_pack_layout(B, r, world, nown, ctx->d_scalars + 3, ctx->stream);            // rank r's packed positions
     bzx_launch_unpack(B, (const uint32_t *)d_packed_r, r, world, nown, grid_for(ctx, nown, 4), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
+    return BZX_OK;
+}
+
+// RLE1Block::new(source, block_size) + Iterator::next (rle1.rs:49-85,245-263) for a source that arrives in pieces:
+// every call returns the blocks that are complete with the bytes seen so far; the last, unfinished block is withheld
+// (its raw bytes are kept in the context) and comes out of a later call, or of the call with final != 0.
+extern "C" int bzx_split_rle1_chunk(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level, int final, uint8_t *blocks_out,
+                                    uint32_t nblk_cap, uint32_t *ns, uint32_t *crcs, uint32_t *nblk_out)
+{
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
+    if (!ctx || !blocks_out || !ns || !crcs || !nblk_out || !level_ok(level) || (len && !raw)) return BZX_E_PARAM;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *nblk_out = 0;
+    int rc = BZX_OK;
+    std::vector<uint8_t> &carry = ctx->split_carry;
+    const size_t total = carry.size() + len;
+    if (total == 0) return BZX_OK;
+    void *d_raw = nullptr;
+    if (hipMalloc(&d_raw, total) != hipSuccess) return BZX_E_NOMEM;
+    uint32_t nblk = 0, use = 0;
+    uint64_t last_start = 0;
+    if (!carry.empty() && hipMemcpyAsync(d_raw, carry.data(), carry.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = BZX_E_HIP;
+    if (!rc && len && hipMemcpyAsync((uint8_t *)d_raw + carry.size(), raw, len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = BZX_E_HIP;
+    if (!rc) rc = split_on_device(ctx, (const uint8_t *)d_raw, total, level, &nblk, 0, 1, &last_start);
+    if (!rc) {
+        use = final ? nblk : nblk - 1;
+        if (use > nblk_cap) rc = BZX_E_OUTBUF;
+    }
+    if (!rc && use) {
+        if (hipMemcpyAsync(ctx->h_blk, ctx->B.blk, use * sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = BZX_E_HIP;
+    }
+    for (uint32_t b = 0; !rc && b < use; b++) {
+        ns[b] = ctx->h_blk[b].n;
+        crcs[b] = ctx->h_blk[b].crc;
+        const uint64_t off = ctx->h_blk[b].in_off;
+        const uint8_t *src = (off & BZX_IN_RAW) ? (const uint8_t *)d_raw + (off & ~BZX_IN_RAW) : ctx->d_in + off;
+        if (ns[b] == 0 || ns[b] > BZX_MAX_BLOCK ||
+            hipMemcpy(blocks_out + (size_t)b * BZX_MAX_BLOCK, src, ns[b], hipMemcpyDeviceToHost) != hipSuccess)
+            rc = BZX_E_HIP;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_raw);
+    if (rc) return rc;
+    // the withheld block's raw bytes: [last_start, total) of (carry | raw)
+    std::vector<uint8_t> next;
+    if (!final) {
+        const size_t ls = (size_t)last_start, cs = carry.size();
+        try {
+            next.reserve(total - ls);
+            if (ls < cs) next.insert(next.end(), carry.begin() + ls, carry.end());
+            const size_t from = ls > cs ? ls - cs : 0;
+            if (len > from) next.insert(next.end(), raw + from, raw + len);
+        } catch (const std::bad_alloc &) {
+            return BZX_E_NOMEM;
+        }
+    }
+    carry.swap(next);
+    *nblk_out = use;
+    return BZX_OK;
+}
+
+// Page-locked host memory for the callers' buffers (copies from/to pageable memory are staged by the runtime and
+// cannot overlap the kernels).
+extern "C" void *bzx_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1, 0) == hipSuccess ? p : nullptr;
+}
+extern "C" void bzx_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+// ---- chunked stream compressor (include/bzx.h: bzx_cstream_*) -----------------------------------------------------
+// The reference's driver reads the input incrementally (RLE1Block<R: Read>, rle1.rs:49-85,245-263), overlaps block
+// production, compression and an ordered writer thread (compress.rs:66-132, bitwriter.rs:77-132).  Here the input
+// arrives in CHUNKS: chunk k is copied to the device while chunk k-1 is compressed and the output of chunk k-2..k-1
+// travels back, on three HIP streams with double buffers.  Block boundaries depend on the whole stream before them
+// (SURVEY.md D1); a chunk is therefore split as "the raw bytes of the last, unfinished block of the previous chunk
+// + the new bytes": the splitter's state is clean at a block start (a block is a whole number of run pieces), so
+// restarting there reproduces exactly the blocks a one-shot split would cut.  All blocks but the last of a chunk
+// are compressed; the last one is withheld until more input (or `final`) arrives.  Chunk outputs are bit-contiguous:
+// the bit phase travels on the device (bzx_layout_kernel), the shared boundary word is OR-merged on the host, header
+// and footer (+ combined CRC, crc.rs:25-27) are written by the host.
+struct bzx_cstream {
+    bzx_ctx *ctx = nullptr;
+    int level = 9;
+    size_t max_chunk = 0, in_cap = 0, out_cap = 0;
+    uint8_t *d_in[2] = {nullptr, nullptr};
+    uint32_t *d_out[2] = {nullptr, nullptr};
+    uint64_t *d_phase = nullptr;            // [0] bit phase of the next chunk, [1] bits of the last laid-out chunk
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_d2h = nullptr;
+    uint64_t *h_info[2] = {nullptr, nullptr};     // pinned: {phase in, bits} of the chunk emitted into d_out[slot]
+    uint32_t *h_w0 = nullptr;                     // pinned: first word of a chunk's output (shared with its predecessor)
+    BzxBlock *h_blk[2] = {nullptr, nullptr};      // pinned: descriptors of the chunk's blocks (CRCs)
+    uint32_t blk_cap = 0;
+    uint32_t k = 0;                         // chunks fed
+    size_t carry_len = 0, carry_start = 0;  // raw bytes of the withheld block inside d_in[(k-1)&1]
+    uint64_t bits = 32;                     // stream bits accounted for so far (header included)
+    uint32_t crc_comb = 0;
+    uint64_t nblk_total = 0, st_rle1 = 0, st_mtf = 0, st_raw = 0;
+    uint32_t st_per = 0;
+    bool pend = false;                      // a chunk's output still sits in d_out[pend_slot]
+    uint32_t pend_slot = 0, pend_nblk = 0;
+    bool finished = false;
+    uint8_t *out = nullptr;
+    size_t cap = 0;
+    size_t need_hint = 0;                   // after BZX_E_OUTBUF: bytes the output needs at least
+};
+
+extern "C" void bzx_cstream_end(bzx_cstream *s)
+{
+    if (!s) return;
+    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    if (s->ctx) (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->s_h2d) (void)hipStreamSynchronize(s->s_h2d);
+    if (s->s_d2h) (void)hipStreamSynchronize(s->s_d2h);
+    for (int i = 0; i < 2; i++) {
+        if (s->d_in[i]) (void)hipFree(s->d_in[i]);
+        if (s->d_out[i]) (void)hipFree(s->d_out[i]);
+        if (s->ev_h2d[i]) (void)hipEventDestroy(s->ev_h2d[i]);
+        if (s->ev_done[i]) (void)hipEventDestroy(s->ev_done[i]);
+        if (s->h_info[i]) (void)hipHostFree(s->h_info[i]);
+        if (s->h_blk[i]) (void)hipHostFree(s->h_blk[i]);
+    }
+    if (s->ev_d2h) (void)hipEventDestroy(s->ev_d2h);
+    if (s->d_phase) (void)hipFree(s->d_phase);
+    if (s->h_w0) (void)hipHostFree(s->h_w0);
+    if (s->s_h2d) (void)hipStreamDestroy(s->s_h2d);
+    if (s->s_d2h) (void)hipStreamDestroy(s->s_d2h);
+    delete s;
+}
+
+// A block covers at most nblockMAX RLE1 bytes = nblockMAX / 5 runs of 255: the withheld raw tail never exceeds this.
+static size_t cstream_max_carry(int level) { return ((size_t)100000 * level / 5 + 2) * 255 + 4096; }
+
+extern "C" int bzx_cstream_begin(bzx_ctx *ctx, int level, size_t max_chunk, bzx_cstream **out)
+{
+    if (!ctx || !out || !level_ok(level)) return BZX_E_PARAM;
+    *out = nullptr;
+    std::unique_lock<std::recursive_mutex> api_lock_(ctx->api_mu);
+    if (max_chunk == 0) max_chunk = (size_t)256 << 20;
+    max_chunk = (max_chunk + 15) & ~(size_t)15;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    bzx_cstream *s = new (std::nothrow) bzx_cstream();
+    if (!s) return BZX_E_NOMEM;
+    s->ctx = ctx;
+    s->level = level;
+    s->max_chunk = max_chunk;
+    s->in_cap = max_chunk + cstream_max_carry(level) + 256;
+    s->out_cap = (s->in_cap + s->in_cap / 50 + 65536) & ~(size_t)255;       // RLE1 +25 % never survives coding: 2 % + slack
+    s->out_cap += s->in_cap / 4;
+    s->blk_cap = (uint32_t)((s->in_cap + s->in_cap / 4) / ((size_t)100000 * level - 19) + 4);
+    bool ok = true;
+    for (int i = 0; i < 2 && ok; i++) {
+        ok = hipMalloc((void **)&s->d_in[i], s->in_cap) == hipSuccess && hipMalloc((void **)&s->d_out[i], s->out_cap) == hipSuccess &&
+             hipEventCreateWithFlags(&s->ev_h2d[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&s->ev_done[i], hipEventDisableTiming) == hipSuccess &&
+             hipHostMalloc((void **)&s->h_info[i], 4 * sizeof(uint64_t), 0) == hipSuccess &&
+             hipHostMalloc((void **)&s->h_blk[i], (size_t)s->blk_cap * sizeof(BzxBlock), 0) == hipSuccess;
+    }
+    ok = ok && hipEventCreateWithFlags(&s->ev_d2h, hipEventDisableTiming) == hipSuccess &&
+         hipMalloc((void **)&s->d_phase, 4 * sizeof(uint64_t)) == hipSuccess &&
+         hipHostMalloc((void **)&s->h_w0, 16, 0) == hipSuccess &&
+         hipStreamCreateWithFlags(&s->s_h2d, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&s->s_d2h, hipStreamNonBlocking) == hipSuccess &&
+         hipMemsetAsync(s->d_phase, 0, 4 * sizeof(uint64_t), ctx->stream) == hipSuccess;
+    if (!ok) {
+        ctx->err = "bzx_cstream_begin: device or pinned allocation failed";
+        bzx_cstream_end(s);
+        return BZX_E_NOMEM;
+    }
+    *out = s;
+    return BZX_OK;
+}
+
+// Brings the output of the chunk parked in d_out[pend_slot] to the caller's buffer (async on the copy-back stream)
+// and accounts for its bits and block CRCs.  The chunk's layout has completed when this is called.
+static int cstream_collect(bzx_cstream *s)
+{
+    bzx_ctx *ctx = s->ctx;
+    if (!s->pend) return BZX_OK;
+    const uint32_t slot = s->pend_slot;
+    // h_info = {phase the NEXT chunk starts with, bits of this chunk}; this chunk started at the phase the host
+    // accounting says
+    const uint64_t phase = s->bits & 31u, cbits = s->h_info[slot][1];
+    if (s->h_info[slot][0] != ((phase + cbits) & 31u)) {
+        ctx->err = "chunked stream: bit phase out of step";
+        return BZX_E_STATE;
+    }
+    const uint64_t nwords = (phase + cbits + 31) >> 5;
+    const size_t off = (size_t)(s->bits >> 5) * 4;
+    if (off + nwords * 4 > s->cap) {
+        ctx->err = "output buffer too small for the compressed stream";
+        s->need_hint = off + (size_t)((phase + cbits + 80 + 7) >> 3);
+        return BZX_E_OUTBUF;
+    }
+    if (nwords * 4 > s->out_cap) {
+        ctx->err = "chunk output larger than its device buffer";
+        return BZX_E_HIP;
+    }
+    HIP_TRY(ctx, hipStreamWaitEvent(s->s_d2h, s->ev_done[slot], 0));
+    if (nwords) {
+        HIP_TRY(ctx, hipMemcpyAsync(s->h_w0, s->d_out[slot], 4, hipMemcpyDeviceToHost, s->s_d2h));
+        if (nwords > 1)
+            HIP_TRY(ctx, hipMemcpyAsync(s->out + off + 4, s->d_out[slot] + 1, (nwords - 1) * 4, hipMemcpyDeviceToHost, s->s_d2h));
+    }
+    HIP_TRY(ctx, hipEventRecord(s->ev_d2h, s->s_d2h));
+    HIP_TRY(ctx, hipEventSynchronize(s->ev_d2h));
+    if (nwords) {
+        // the first word is shared with the predecessor (or with nothing: then the bytes there are still zero)
+        uint8_t w[4];
+        memcpy(w, s->h_w0, 4);
+        if (phase == 0) memcpy(s->out + off, w, 4);
+        else for (int i = 0; i < 4; i++) s->out[off + i] |= w[i];
+    }
+    for (uint32_t b = 0; b < s->pend_nblk; b++) {
+        const BzxBlock &d = s->h_blk[slot][b];
+        s->crc_comb = ((s->crc_comb << 1) | (s->crc_comb >> 31)) ^ d.crc;
+        s->st_rle1 += d.n;
+        s->st_mtf += d.n_mtf;
+        s->st_per += (d.status & BZX_ST_PERIODIC) ? 1u : 0u;
+    }
+    s->nblk_total += s->pend_nblk;
+    s->bits += cbits;
+    s->pend = false;
+    return BZX_OK;
+}
+
+// Back to the state after bzx_cstream_begin (buffers kept): a new stream on the same object.
+static size_t cstream_chunk_of(const bzx_cstream *s) { return s->max_chunk; }
+static size_t cstream_need_hint(const bzx_cstream *s) { return s->need_hint; }
+
+static int cstream_reset(bzx_cstream *s, int level)
+{
+    bzx_ctx *ctx = s->ctx;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(s->s_h2d));
+    HIP_TRY(ctx, hipStreamSynchronize(s->s_d2h));
+    HIP_TRY(ctx, hipMemsetAsync(s->d_phase, 0, 4 * sizeof(uint64_t), ctx->stream));
+    s->level = level;
+    s->k = 0;
+    s->carry_len = s->carry_start = 0;
+    s->bits = 32;
+    s->crc_comb = 0;
+    s->nblk_total = s->st_rle1 = s->st_mtf = s->st_raw = 0;
+    s->st_per = 0;
+    s->pend = false;
+    s->finished = false;
+    return BZX_OK;
+}
+
+extern "C" int bzx_cstream_feed(bzx_cstream *s, const uint8_t *raw, size_t len, int final, uint8_t *out, size_t cap,
+                                size_t *produced)
+{
+    if (!s || !s->ctx || !out || !produced || (len && !raw) || len > s->max_chunk || cap < 16) return BZX_E_PARAM;
+    bzx_ctx *ctx = s->ctx;
+    std::unique_lock<std::recursive_mutex> api_lock_(ctx->api_mu);
+    if (s->finished) return BZX_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (s->k == 0) {
+        memset(out, 0, cap < 64 ? cap : 64);
+        out[0] = 'B'; out[1] = 'Z'; out[2] = 'h'; out[3] = (uint8_t)('0' + s->level);
+    }
+    s->out = out;
+    s->cap = cap;
+    const uint32_t slot = s->k & 1u;
+    const size_t total = s->carry_len + len;
+    // the device buffer of this slot was last read by chunk k-2; its kernels are long done when k-1's results were
+    // collected, but the copy stream does not know that: make it wait
+    if (s->k >= 2) HIP_TRY(ctx, hipStreamWaitEvent(s->s_h2d, s->ev_done[slot], 0));
+    if (len) {
+        HIP_TRY(ctx, hipMemcpyAsync(s->d_in[slot] + s->carry_len, raw, len, hipMemcpyHostToDevice, s->s_h2d));
+    }
+    HIP_TRY(ctx, hipEventRecord(s->ev_h2d[slot], s->s_h2d));
+    if (s->carry_len)     // the withheld block's raw bytes move to the front of this chunk (after the kernels that read them)
+        HIP_TRY(ctx, hipMemcpyAsync(s->d_in[slot], s->d_in[slot ^ 1u] + s->carry_start, s->carry_len, hipMemcpyDeviceToDevice,
+                                    ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_h2d[slot], 0));
+    uint32_t nblk = 0, use = 0;
+    uint64_t last_start = 0;
+    int rc = BZX_OK;
+    if (total) {
+        ctx->B.blk_first = 0;
+        ctx->B.blk_step = 1;
+        rc = split_on_device(ctx, s->d_in[slot], total, s->level, &nblk, 0, 1, &last_start);     // (synchronises)
+        if (rc) return rc;
+        use = final ? nblk : nblk - 1;
+        if (use > s->blk_cap) {
+            ctx->err = "chunked stream: more blocks in a chunk than provisioned";
+            return BZX_E_HIP;
+        }
+    }
+    // the previous chunk was laid out before this chunk's split ran: its sizes are on the host now
+    if (!total) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = cstream_collect(s))) return rc;
+    if (use) {
+        if ((rc = run_stages(ctx, use, STG_ALL, -1, s->d_out[slot], s->out_cap, s->d_phase))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(s->h_info[slot], s->d_phase, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(s->h_blk[slot], ctx->B.blk, (size_t)use * sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipEventRecord(s->ev_done[slot], ctx->stream));
+    if (use) {
+        s->pend = true;
+        s->pend_slot = slot;
+        s->pend_nblk = use;
+    }
+    if (!final && total) {
+        s->carry_start = (size_t)last_start;
+        s->carry_len = total - (size_t)last_start;
+    } else {
+        s->carry_len = 0;
+        s->carry_start = 0;
+    }
+    s->k++;
+    if (final) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = cstream_collect(s))) return rc;
+        collect_stage_times(ctx);
+        // footer: magic, combined CRC (crc.rs:25-27), zero padding to a byte (bitwriter.rs:103-114,158-172)
+        const uint64_t end = s->bits;
+        const size_t need = (size_t)((end + 80 + 7) >> 3);
+        if (need > cap) {
+            ctx->err = "output buffer too small for the compressed stream";
+            s->need_hint = need;
+            return BZX_E_OUTBUF;
+        }
+        const uint8_t foot[10] = {0x17, 0x72, 0x45, 0x38, 0x50, 0x90, (uint8_t)(s->crc_comb >> 24), (uint8_t)(s->crc_comb >> 16),
+                                  (uint8_t)(s->crc_comb >> 8), (uint8_t)s->crc_comb};
+        const size_t ebyte = (size_t)(end >> 3);
+        const uint32_t sh = (uint32_t)(end & 7u);
+        // bytes from the end of the last word written on are untouched so far: clear, then OR the shifted footer in
+        const size_t clear_from = (size_t)((end + 31) >> 5) * 4;
+        for (size_t i = clear_from; i < need; i++) out[i] = 0;
+        for (int i = 0; i < 10; i++) {
+            out[ebyte + i] |= (uint8_t)(foot[i] >> sh);
+            if (sh) out[ebyte + i + 1] |= (uint8_t)(foot[i] << (8 - sh));
+        }
+        *produced = need;
+        s->finished = true;
+        ctx->stats.nblk = (uint32_t)s->nblk_total;
+        ctx->stats.n_periodic = s->st_per;
+        ctx->stats.rle1_bytes = s->st_rle1;
+        ctx->stats.mtf_symbols = s->st_mtf;
+        ctx->stats.raw_bytes = s->st_raw + len;
+        ctx->stats.out_bits = (uint64_t)need * 8;
+        return BZX_OK;
+    }
+    s->st_raw += len;
+    // bytes that can no longer change: everything before the word the next chunk starts in
+    *produced = (size_t)(s->bits >> 5) * 4;
     return BZX_OK;
 }
 

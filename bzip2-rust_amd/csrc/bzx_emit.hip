@@ -258,12 +258,15 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
 
 // out_bit of every block: first_bit + exclusive scan of block sizes (stream mode, stride_bits == 0)
 // or b * stride_bits (per-block mode).  total[0] = first_bit + sum of sizes.
+// phase (optional, chunked streams): the first bit comes from phase[0] on the device (bit phase 0..31 left by the
+// previous chunk of the stream); afterwards phase[0] = phase of the next chunk, phase[1] = bits of this one.
 __global__ __launch_bounds__(EMIT_NT) void bzx_layout_kernel(BzxBatch B, uint64_t first_bit, uint64_t stride_bits,
-                                                            uint64_t *total)
+                                                            uint64_t *total, uint64_t *phase)
 {
     __shared__ uint64_t l_wsum[EMIT_NW];
     __shared__ uint64_t l_carry;
     const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
+    if (phase) first_bit = phase[0];
     if (tid == 0) l_carry = first_bit;
     __syncthreads();
     for (uint32_t b0 = 0; b0 < B.nblk; b0 += EMIT_NT) {
@@ -287,7 +290,13 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_layout_kernel(BzxBatch B, uint64_
         if (tid == 0) l_carry = carry + tot;
         __syncthreads();
     }
-    if (tid == 0) total[0] = l_carry;
+    if (tid == 0) {
+        total[0] = l_carry;
+        if (phase) {
+            phase[1] = l_carry - first_bit;
+            phase[0] = l_carry & 31u;
+        }
+    }
 }
 
 // "BZh<level>" at bit 0, footer magic + combined CRC behind the last block; out_bytes[0] = stream length.
@@ -445,9 +454,10 @@ void bzx_launch_emit(const BzxBatch &B, uint32_t grid, hipStream_t stream)
 }
 
 void bzx_launch_layout(const BzxBatch &B, uint64_t first_bit, uint64_t stride_bits, uint64_t *d_total_bits,
-                       hipStream_t stream)
+                       hipStream_t stream, uint64_t *d_phase)
 {
-    hipLaunchKernelGGL(bzx_layout_kernel, dim3(1), dim3(EMIT_NT), 0, stream, B, first_bit, stride_bits, d_total_bits);
+    hipLaunchKernelGGL(bzx_layout_kernel, dim3(1), dim3(EMIT_NT), 0, stream, B, first_bit, stride_bits, d_total_bits,
+                       d_phase);
 }
 
 void bzx_launch_stream_frame(const BzxBatch &B, int level, const uint64_t *d_total_bits, uint64_t *d_out_bytes,

@@ -131,6 +131,38 @@ int bzx_shard_assemble_rank(bzx_ctx *ctx, const void *d_packed_r, uint32_t r, vo
 /* bzx_shard_assemble_* only enqueue work on the context's stream; wait for it here (or on the caller's stream). */
 int bzx_ctx_sync(bzx_ctx *ctx);
 
+/*
+ * Streaming forms.  The reference reads its input incrementally (RLE1Block::new(source: R, ...), rle1.rs:49-85;
+ * Iterator::next :245-263) and overlaps production, compression and an ordered writer (compress.rs:66-132,
+ * bitwriter.rs:77-132).  Block boundaries depend on everything before them, so a chunked caller
+ * cannot split chunks independently; these entry points keep the state between calls.
+ *
+ * bzx_split_rle1_chunk: RLE1Block over a source that arrives in pieces.  Returns the blocks that are complete with
+ * the bytes seen so far (layout as bzx_split_rle1); the last, unfinished block is withheld inside the context (its
+ * pending run and partial block) and comes out of a later call or of the call with final != 0.  One stream per
+ * context at a time.
+ */
+int bzx_split_rle1_chunk(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level, int final, uint8_t *blocks_out,
+                         uint32_t nblk_cap, uint32_t *ns, uint32_t *crcs, uint32_t *nblk_out);
+
+/*
+ * bzx_cstream_*: whole-stream compressor for host buffers fed in chunks of at most max_chunk bytes (0 = 256 MiB);
+ * device memory is bounded by the chunk size, not by the input.  Copy of chunk k+1 to the device, compression of
+ * chunk k and copy-back of chunk k-1 overlap (three HIP streams, double buffers); pass page-locked buffers
+ * (bzx_host_alloc, or memory the caller registered with HIP) for truly asynchronous copies.
+ *   feed: consumes raw[0..len); `out`/`cap` is the WHOLE output buffer, the same on every call; *produced = bytes
+ *   of it that are final so far (a caller may write out[flushed..*produced) to its file after every call).
+ *   The call with final != 0 (len may be 0) completes the stream: *produced = length of the .bz2.
+ * bzx_compress_buffer is this over a whole buffer.
+ */
+typedef struct bzx_cstream bzx_cstream;
+int bzx_cstream_begin(bzx_ctx *ctx, int level, size_t max_chunk, bzx_cstream **out);
+int bzx_cstream_feed(bzx_cstream *s, const uint8_t *raw, size_t len, int final, uint8_t *out, size_t cap,
+                     size_t *produced);
+void bzx_cstream_end(bzx_cstream *s);
+void *bzx_host_alloc(size_t bytes);     /* page-locked host memory (NULL on failure) */
+void bzx_host_free(void *p);
+
 /* Per-call telemetry of the last bzx_compress_device/_buffer/_blocks call. */
 typedef struct {
     uint32_t nblk;

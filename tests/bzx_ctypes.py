@@ -155,6 +155,56 @@ class BzxLib:
         self._check(self.lib.bzx_split_rle1(self.ctx, data, len(data), level, slabs, cap, ns, crcs, C.byref(nb)))
         return [(slabs.raw[b * 900000:b * 900000 + ns[b]], crcs[b]) for b in range(nb.value)]
 
+    def cstream_compress(self, data: bytes, level=9, chunk=1 << 20, max_chunk=None, pinned=False):
+        """bzx_cstream_*: feed `data` in pieces of `chunk` bytes (an int, or a list of piece lengths); returns the .bz2."""
+        L = self.lib
+        L.bzx_cstream_begin.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.bzx_cstream_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                       C.POINTER(C.c_size_t)]
+        L.bzx_cstream_end.argtypes = [C.c_void_p]
+        pieces = chunk if isinstance(chunk, (list, tuple)) else None
+        mc = max_chunk or (max(pieces) if pieces else chunk)
+        s = C.c_void_p()
+        self._check(L.bzx_cstream_begin(self.ctx, level, mc, C.byref(s)))
+        cap = len(data) + len(data) // 50 + 4096
+        out = C.create_string_buffer(cap)
+        src = C.create_string_buffer(data, len(data)) if data else C.create_string_buffer(1)
+        produced = C.c_size_t()
+        try:
+            off, i, last = 0, 0, 0
+            while True:
+                n = min(len(data) - off, pieces[i % len(pieces)] if pieces else chunk)
+                fin = off + n >= len(data)
+                self._check(L.bzx_cstream_feed(s, C.addressof(src) + off, n, int(fin), out, cap, C.byref(produced)))
+                assert produced.value >= last
+                last = produced.value
+                off += n
+                i += 1
+                if fin:
+                    break
+        finally:
+            L.bzx_cstream_end(s)
+        return out.raw[:produced.value]
+
+    def split_rle1_chunks(self, data: bytes, level=9, chunk=1 << 16):
+        """bzx_split_rle1_chunk over pieces of `chunk` bytes -> list of (block bytes, crc), as split_rle1."""
+        L = self.lib
+        L.bzx_split_rle1_chunk.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_uint32,
+                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        capb = 8
+        buf = C.create_string_buffer(capb * 900000)
+        ns, crcs, nb = (C.c_uint32 * capb)(), (C.c_uint32 * capb)(), C.c_uint32()
+        out, off = [], 0
+        while True:
+            n = min(chunk, len(data) - off)
+            fin = off + n >= len(data)
+            self._check(L.bzx_split_rle1_chunk(self.ctx, data[off:off + n], n, level, int(fin), buf, capb, ns, crcs, C.byref(nb)))
+            for b in range(nb.value):
+                out.append((buf.raw[b * 900000:b * 900000 + ns[b]], crcs[b]))
+            off += n
+            if fin:
+                return out
+
     def stats(self):
         st = BzxStats()
         self._check(self.lib.bzx_get_stats(self.ctx, C.byref(st)))

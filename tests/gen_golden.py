@@ -23,7 +23,46 @@ RECIPES = {
     "zeros_2MiB_l9": ({"kind": "zeros", "n": 2 << 20}, 9),
     "runs_mixed_l9": ({"kind": "runs", "n": 3_000_000, "seed": 17}, 9),
     "allbytes_l1": ({"kind": "cycle256", "n": 300_000}, 1),
+    # BASELINE.json configs at full size (sha256 of libbz2's stream; minutes of single-thread libbz2 to regenerate)
+    "config3_text_1GiB_l9": ({"kind": "synthtext", "n": 1 << 30}, 9),
+    "config5a_zeros_256MiB_l9": ({"kind": "zeros", "n": 256 << 20}, 9),
+    "config5b_random_256MiB_l9": ({"kind": "random", "n": 256 << 20}, 9),
 }
+
+# Periodic blocks u^k: the 24-bit origPtr is whatever libbz2's sorter leaves among the k identical
+# rotations.  (unit recipe, k): unit = bytes.fromhex(hex) or a seeded random unit of `len` bytes over `alpha` symbols.
+PERIODIC = [
+    ({"zeros": 255}, 2), ({"zeros": 255}, 1999), ({"zeros": 255}, 20000), ({"zeros": 255}, 179996),
+    ({"zeros": 1020}, 3), ({"zeros": 259}, 1000),
+    ({"hex": "6162"}, 2), ({"hex": "6162"}, 50), ({"hex": "6162"}, 5000), ({"hex": "6162"}, 40000),
+    ({"hex": "00000001"}, 3000), ({"hex": "61626361626364"}, 15),
+    ({"hex": "61626361626364"}, 1400), ({"hex": "ff"}, 12345), ({"hex": "0001"}, 449990),
+    ({"len": 7, "alpha": 3, "seed": 1}, 3), ({"len": 19, "alpha": 2, "seed": 2}, 600), ({"len": 100, "alpha": 4, "seed": 3}, 77),
+    ({"len": 1000, "alpha": 200, "seed": 4}, 9), ({"len": 4999, "alpha": 26, "seed": 5}, 2), ({"len": 5000, "alpha": 26, "seed": 6}, 2),
+    ({"len": 10007, "alpha": 5, "seed": 7}, 80), ({"len": 280001, "alpha": 26, "seed": 8}, 3), ({"len": 440003, "alpha": 250, "seed": 9}, 2),
+    ({"len": 64, "alpha": 2, "seed": 10}, 14000), ({"len": 3, "alpha": 3, "seed": 11}, 299993),
+]
+
+
+def periodic_unit(r):
+    if "zeros" in r:
+        return b"\0" * r["zeros"]          # RLE1 turns 255 zeros into 00 00 00 00 fb: the image is periodic too
+    if "hex" in r:
+        return bytes.fromhex(r["hex"])
+    import random
+    rnd = random.Random(r["seed"])
+    syms = rnd.sample(range(256), r["alpha"])
+    while True:
+        u = bytes(rnd.choice(syms) for _ in range(r["len"]))
+        # the unit itself must not be a power of a shorter word, or the recorded k would be wrong
+        if not any(r["len"] % p == 0 and u == u[:p] * (r["len"] // p) for p in range(1, r["len"] // 2 + 1) if r["len"] % p == 0):
+            return u
+
+
+def orig_ptr_of_stream(z):
+    """origPtr of the FIRST block of a .bz2: 24 bits after 'BZh9' (32) + block magic (48) + CRC (32) + randomised (1)."""
+    v = int.from_bytes(z[:20], "big")
+    return (v >> (160 - 113 - 24)) & 0xFFFFFF
 
 
 def make_input(oracle, r):
@@ -54,6 +93,21 @@ def make_input(oracle, r):
 def main():
     from bzx_ctypes import Oracle
     o = Oracle()
+    # periodic blocks: single-block inputs; the block libbz2 sorts is the RLE1 image of the input (oracle split,
+    # itself pinned against libbz2 by the stream tests); origPtr is read from libbz2's stream
+    periodic = []
+    for unit_r, k in PERIODIC:
+        raw = periodic_unit(unit_r) * k
+        blocks = o.split_rle1(raw, 9)
+        assert len(blocks) == 1, (unit_r, k, len(blocks))
+        image = blocks[0][0]
+        z = bz2.compress(raw, 9)
+        periodic.append({"unit": unit_r, "k": k, "raw_len": len(raw), "n": len(image),
+                         "sha256": hashlib.sha256(image).hexdigest(), "orig_ptr": orig_ptr_of_stream(z)})
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "periodic.json")
+    json.dump({"generator": "tests/gen_golden.py", "libbz2": "1.0.8 (python bz2)", "blocks": periodic},
+              open(path, "w"), indent=1, sort_keys=True)
+    print("wrote", path)
     streams = {}
     for name, (recipe, level) in RECIPES.items():
         data = make_input(o, recipe)

@@ -16,12 +16,19 @@ from bzx_ctypes import EMU_PATH, BzxLib, Oracle  # noqa: E402
 
 def main():
     rank, world, port, nbytes = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    kind = sys.argv[5] if len(sys.argv) > 5 else "text"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
     dist.init_process_group("gloo", rank=rank, world_size=world)
     level = 1
     o = Oracle()
-    data = np.frombuffer(o.synthtext(nbytes) , dtype=np.uint8).copy()
+    if kind == "runs":
+        from gen_golden import make_input
+        # zeros (one long run across several blocks' worth of input), then runs of 1..600, then text
+        mix = b"\0" * (nbytes // 3) + make_input(o, {"kind": "runs", "n": nbytes // 3, "seed": 5}) + o.synthtext(nbytes // 3)
+        data = np.frombuffer(mix, dtype=np.uint8).copy()
+    else:
+        data = np.frombuffer(o.synthtext(nbytes), dtype=np.uint8).copy()
     raw = np.zeros(data.nbytes + 64, dtype=np.uint8)
     off = (-raw.ctypes.data) % 16
     raw[off:off + data.nbytes] = data
@@ -66,7 +73,7 @@ def main():
         z = out.numpy().tobytes()[:ol.value]
         want = bz2.compress(data.tobytes(), level)
         assert z == want, (len(z), len(want))
-        assert nblk.value == 3
+        assert nblk.value == len(o.split_rle1(data.tobytes(), level))
         print("SHARD_OK", nblk.value, len(z))
     dist.barrier()
     dist.destroy_process_group()

@@ -93,3 +93,19 @@ def test_emu_split_and_stream(emu, oracle):
         assert emu.split_rle1(data, level) == oracle.split_rle1(data, level)
     data = oracle.synthtext(60000) + b"\0" * 2000 + oracle.synthtext(45000)
     assert emu.compress_buffer(data, 1) == bz2.compress(data, 1)
+
+
+def test_emu_chunked_stream_and_chunked_split(emu, oracle):
+    """bzx_cstream_* / bzx_split_rle1_chunk (RLE1Block over a source that arrives in pieces, rle1.rs:49-85,245-263):
+    chunk borders inside long runs, at block-full edges, one-byte chunks, an empty final call."""
+    rnd = random.Random(3)
+    runs = bytearray()
+    while len(runs) < 260000:
+        runs += bytes([rnd.choice(b"ab\0")]) * rnd.randint(1, 700)
+    cases = [(b"", 1, 1000), (b"xyz", 9, 2), (oracle.synthtext(250000), 1, 70000), (bytes(runs), 1, 33333),
+             (b"\0" * 3000000, 1, 900000),
+             (oracle.synthtext(99981) + b"\0" * 5000 + oracle.synthtext(120000), 1, [1, 99980, 4999, 3, 50000])]
+    for data, level, chunk in cases:
+        assert emu.cstream_compress(data, level, chunk) == bz2.compress(data, level), (len(data), chunk)
+    for data, level, chunk in cases[1:5]:
+        assert emu.split_rle1_chunks(data, level, chunk) == oracle.split_rle1(data, level), (len(data), chunk)

@@ -128,7 +128,15 @@ def test_stream_golden(bzx, oracle, name):
     out = bzx.compress_buffer(data, g["level"])
     assert len(out) == g["bz2_len"]
     assert hashlib.sha256(out).hexdigest() == g["bz2_sha256"]
-    assert out == bz2.compress(data, g["level"])
+    if len(data) <= (8 << 20):
+        assert out == bz2.compress(data, g["level"])
+    else:
+        # BASELINE configs[2] / configs[4] at FULL size (1 GiB text, 256 MiB zeros, 256 MiB random): besides libbz2's
+        # committed sha256 above, the oracle's multi-threaded driver must give the same bytes, and libbz2 must decode
+        # the head of the device stream back to the head of the input
+        assert out == oracle.compress_mt(data, g["level"])
+        head = bz2.BZ2Decompressor().decompress(out[:3 << 20], max_length=32 << 20)
+        assert len(head) > 0 and data[:len(head)] == head
 
 
 def test_stream_matches_oracle_and_roundtrips(bzx, oracle):
@@ -157,6 +165,77 @@ def test_periodic_blocks_stream(bzx, oracle):
         out = bzx.compress_buffer(data, level)
         assert out == bz2.compress(data, level), (len(data), level)
         assert bzx.stats().n_periodic >= 1
+
+
+PERIODIC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "periodic.json")))
+
+
+def test_periodic_orig_ptr_fixture(bzx, oracle):
+    """SURVEY.md D6 on the committed (u, k) sweep: for blocks that are a power u^k the last column is tie-invariant
+    and origPtr must be the one libbz2 1.0.8 wrote (tests/golden/periodic.json, read out of libbz2's streams)."""
+    from gen_golden import periodic_unit
+    for g in PERIODIC["blocks"]:
+        raw = periodic_unit(g["unit"]) * g["k"]
+        image = oracle.split_rle1(raw, 9)[0][0]
+        assert len(image) == g["n"] and hashlib.sha256(image).hexdigest() == g["sha256"]
+        L, orig, status = bzx.stage_bwt(image)
+        assert orig == g["orig_ptr"], (g["unit"], g["k"], orig, g["orig_ptr"])
+        assert L == oracle.bwt(image)[0], (g["unit"], g["k"])
+        is_power = (image + image).find(image, 1) < len(image)      # the RLE1 image itself is u^k, k > 1
+        assert bool(status & 1) == is_power, (g["unit"], g["k"])    # BZX_ST_PERIODIC
+
+
+def test_stream_assembler_fed_with_device_block_images(bzx, oracle):
+    """The reference's structure end to end (compress.rs:66-132): RLE1Block producer -> compress_block on the
+    device (batched) -> BitWriter.  Here: bzx_split_rle1 -> bzx_compress_blocks -> bzx_stream_* (host assembler),
+    every stage through the C ABI, against libbz2."""
+    import ctypes as C
+    L = bzx.lib
+    L.bzx_stream_begin.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.bzx_stream_append_block.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint8]
+    L.bzx_stream_finish.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    L.bzx_stream_free.argtypes = [C.c_void_p]
+    data = oracle.synthtext(700_000) + b"\xff" * 70_000 + oracle.randbytes(400_000) + b"ab" * 5
+    for level in (1, 3):
+        blocks = bzx.split_rle1(data, level)
+        assert blocks == oracle.split_rle1(data, level)
+        images = bzx.compress_blocks([b for b, _ in blocks], [c for _, c in blocks])
+        s = C.c_void_p()
+        assert L.bzx_stream_begin(level, C.byref(s)) == 0
+        for img, pad in images:
+            assert L.bzx_stream_append_block(s, img, len(img), pad) == 0
+        p, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        assert L.bzx_stream_finish(s, C.byref(p), C.byref(n)) == 0
+        z = bytes(p[:n.value])
+        L.bzx_stream_free(s)
+        assert z == bz2.compress(data, level), level
+
+
+def test_chunked_stream_compressor(bzx, oracle):
+    """bzx_cstream_* on the device: the input arrives in chunks of 64 KiB ... 64 MiB; chunk borders fall inside runs
+    longer than 255, exactly at block-full edges and one byte around them; the stream must be libbz2's, whatever the
+    chunking (the splitter carries the pending run and the partial block from call to call)."""
+    nmax = 899981
+    text = oracle.synthtext(3 * nmax + 12345)
+    runs = (b"\xff" * 1000 + b"abc") * 3000 + b"\0" * 2_000_000 + oracle.synthtext(500_000)
+    for data, level, chunks in (
+            (text, 9, [65536]), (text, 9, [nmax]), (text, 9, [nmax - 1, 1, 1, nmax]), (text, 9, [nmax + 1]),
+            (text, 9, [1 << 20, 123]), (runs, 9, [65536]), (runs, 9, [1000 * 700 + 130, 777]), (runs, 1, [99981, 5]),
+            (b"\0" * (70 << 20), 9, [1 << 20]), (oracle.randbytes(5 << 20), 5, [(1 << 20) + 1])):
+        want = bz2.compress(data, level)
+        assert bzx.cstream_compress(data, level, chunks, max_chunk=max(chunks)) == want, (len(data), level, chunks)
+    big = oracle.synthtext(150 << 20)
+    want = oracle.compress_mt(big, 9)
+    assert bzx.cstream_compress(big, 9, 64 << 20) == want
+    assert bzx.compress_buffer(big, 9) == want
+
+
+def test_chunked_split(bzx, oracle):
+    """bzx_split_rle1_chunk == one-shot split, for pieces of any size."""
+    runs = (b"\xff" * 1000 + b"abc") * 2500 + b"\0" * 1_000_000 + oracle.synthtext(1_900_000)
+    want = oracle.split_rle1(runs, 9)
+    for chunk in (65536, 899981, 1 << 20, 5_000_000):
+        assert bzx.split_rle1_chunks(runs, 9, chunk) == want, chunk
 
 
 def test_large_roundtrip_properties(bzx, oracle):

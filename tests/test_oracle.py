@@ -73,9 +73,26 @@ def test_golden_streams(oracle, name):
     g = GOLDEN["streams"][name]
     data = make_input(oracle, g["input"])
     assert len(data) == g["raw_len"] and hashlib.sha256(data).hexdigest() == g["raw_sha256"]
-    out, _ = oracle.compress(data, g["level"])
+    # (the full-size BASELINE configs go through the multi-threaded driver: same bytes, minutes less)
+    out = oracle.compress(data, g["level"])[0] if len(data) <= (64 << 20) else oracle.compress_mt(data, g["level"], 8)
     assert len(out) == g["bz2_len"]
     assert hashlib.sha256(out).hexdigest() == g["bz2_sha256"]
+
+
+def test_periodic_orig_ptr_fixture(oracle):
+    """origPtr of blocks that are a power u^k is whatever libbz2's sorter leaves; the committed sweep
+    (tests/golden/periodic.json, read out of libbz2 1.0.8 streams by tests/gen_golden.py) pins the oracle's block
+    sorter, which the device's periodic path is compared with."""
+    import json
+    import os
+    from gen_golden import periodic_unit
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "periodic.json")))
+    assert len(fx["blocks"]) >= 20
+    for g in fx["blocks"]:
+        raw = periodic_unit(g["unit"]) * g["k"]
+        image = oracle.split_rle1(raw, 9)[0][0]
+        assert len(image) == g["n"] and hashlib.sha256(image).hexdigest() == g["sha256"]
+        assert oracle.bwt(image)[1] == g["orig_ptr"], (g["unit"], g["k"])
 
 
 def test_live_libbz2_edge_cases(oracle):
