@@ -281,6 +281,7 @@ extern "C" void bzx_ctx_destroy(bzx_ctx *ctx)
         ctx->cs = nullptr;
     }
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     free_all(ctx->slabs);
     free_all(ctx->slot_allocs);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -303,7 +304,10 @@ extern "C" void bzx_ctx_destroy(bzx_ctx *ctx)
 extern "C" int bzx_ctx_set_stream(bzx_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return BZX_E_PARAM;
+    std::unique_lock<std::recursive_mutex> api_lock_(ctx->api_mu);
+    (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
@@ -313,6 +317,7 @@ extern "C" int bzx_ctx_set_stream(bzx_ctx *ctx, void *hip_stream)
 extern "C" int bzx_get_stats(const bzx_ctx *ctx, bzx_stats *out)
 {
     if (!ctx || !out) return BZX_E_PARAM;
+    std::unique_lock<std::recursive_mutex> api_lock_(const_cast<bzx_ctx *>(ctx)->api_mu);
     *out = ctx->stats;
     return BZX_OK;
 }
@@ -364,7 +369,7 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         Br.redo = 1;
         Br.ctr_bwt = BZX_CTR_REDO_FETCH;
         bzx_launch_bwt(Br, grid_for(ctx, nblk, per_cu), ctx->stream);
-        bzx_launch_periodic(B, 16, ctx->stream);
+        bzx_launch_periodic(B, ctx->n_slots < 64 ? ctx->n_slots : 64, ctx->stream);
     } else if ((stages & STG_BWT) && nblk) {
         uint32_t per_cu = bzx_bwt_max_blocks_per_cu();
         uint32_t grid = grid_for(ctx, nblk, per_cu);
@@ -682,7 +687,9 @@ extern "C" int bzx_compress_blocks(bzx_ctx *ctx, uint32_t nblk, const uint8_t *c
         st.mtf_symbols += d.n_mtf;
         st.out_bits += d.bits;
         if (bytes > BZX_OUT_STRIDE) {
+            // cannot happen: an image is at most n * 17/8 + tables, and the emit kernel clips at the slab end
             ctx->err = "block image larger than its device slab";
+            (void)hipStreamSynchronize(ctx->stream);       // copies into earlier callers' buffers are in flight
             return BZX_E_HIP;
         }
         if (bytes > caps[b]) {
@@ -690,8 +697,12 @@ extern "C" int bzx_compress_blocks(bzx_ctx *ctx, uint32_t nblk, const uint8_t *c
             out_lens[b] = bytes;
             continue;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(outs[b], (const uint8_t *)ctx->d_outbuf + (size_t)b * BZX_OUT_STRIDE, bytes,
-                                    hipMemcpyDeviceToHost, ctx->stream));
+        if (hipMemcpyAsync(outs[b], (const uint8_t *)ctx->d_outbuf + (size_t)b * BZX_OUT_STRIDE, bytes, hipMemcpyDeviceToHost,
+                           ctx->stream) != hipSuccess) {
+            ctx->err = "hipMemcpyAsync(block image) failed";
+            (void)hipStreamSynchronize(ctx->stream);       // earlier copies into caller buffers are in flight
+            return BZX_E_HIP;
+        }
         out_lens[b] = bytes;
         pads[b] = (uint8_t)((8 - (d.bits & 7)) & 7);
     }
@@ -714,7 +725,11 @@ extern "C" int bzx_compress_block(bzx_ctx *ctx, const uint8_t *blk, size_t n, ui
     rq.out = out;
     rq.cap = cap;
     std::unique_lock<std::mutex> lk(ctx->bq_mu);
-    ctx->bq_pending.push_back(&rq);
+    try {
+        ctx->bq_pending.push_back(&rq);
+    } catch (const std::bad_alloc &) {
+        return BZX_E_NOMEM;                      // (nothing may unwind across the C ABI)
+    }
     while (!rq.done) {
         if (ctx->bq_leader) {
             ctx->bq_cv.wait(lk);
@@ -723,31 +738,38 @@ extern "C" int bzx_compress_block(bzx_ctx *ctx, const uint8_t *blk, size_t n, ui
         ctx->bq_leader = true;
         ctx->bq_cv.wait_for(lk, std::chrono::microseconds(300));          // collection window (lock released)
         std::vector<BlockReq *> batch;
-        batch.swap(ctx->bq_pending);
+        batch.swap(ctx->bq_pending);                                      // (swap does not allocate)
         lk.unlock();
         const uint32_t nb = (uint32_t)batch.size();
-        std::vector<const uint8_t *> blks(nb);
-        std::vector<size_t> ns(nb), caps(nb), lens(nb, 0);
-        std::vector<uint32_t> crcs(nb);
-        std::vector<uint8_t *> outs(nb);
-        std::vector<uint8_t> pads(nb, 0);
-        for (uint32_t i = 0; i < nb; i++) {
-            blks[i] = batch[i]->blk;
-            ns[i] = batch[i]->n;
-            crcs[i] = batch[i]->crc;
-            outs[i] = batch[i]->out;
-            caps[i] = batch[i]->cap;
+        int rc = BZX_OK;
+        std::vector<size_t> lens;
+        try {
+            std::vector<const uint8_t *> blks(nb);
+            std::vector<size_t> ns(nb), caps(nb);
+            std::vector<uint32_t> crcs(nb);
+            std::vector<uint8_t *> outs(nb);
+            std::vector<uint8_t> pads(nb, 0);
+            lens.assign(nb, 0);
+            for (uint32_t i = 0; i < nb; i++) {
+                blks[i] = batch[i]->blk;
+                ns[i] = batch[i]->n;
+                crcs[i] = batch[i]->crc;
+                outs[i] = batch[i]->out;
+                caps[i] = batch[i]->cap;
+            }
+            rc = nb ? bzx_compress_blocks(ctx, nb, blks.data(), ns.data(), crcs.data(), outs.data(), caps.data(),
+                                          lens.data(), pads.data())
+                    : BZX_OK;
+            for (uint32_t i = 0; i < nb; i++) batch[i]->pad = pads[i];
+        } catch (const std::bad_alloc &) {
+            rc = BZX_E_NOMEM;                    // every request of the batch fails; nobody is left waiting
         }
-        const int rc = nb ? bzx_compress_blocks(ctx, nb, blks.data(), ns.data(), crcs.data(), outs.data(), caps.data(),
-                                                lens.data(), pads.data())
-                          : BZX_OK;
         lk.lock();
         for (uint32_t i = 0; i < nb; i++) {
             BlockReq *q = batch[i];
-            q->out_len = lens[i];
-            q->pad = pads[i];
+            q->out_len = i < lens.size() ? lens[i] : 0;
             // a block whose image did not fit reports that; its neighbours in the batch are fine
-            q->rc = rc == BZX_E_OUTBUF ? (lens[i] > caps[i] ? BZX_E_OUTBUF : BZX_OK) : rc;
+            q->rc = rc == BZX_E_OUTBUF ? (q->out_len > q->cap ? BZX_E_OUTBUF : BZX_OK) : rc;
             q->done = true;
         }
         ctx->bq_leader = false;
@@ -820,7 +842,10 @@ extern "C" int bzx_compress_device(bzx_ctx *ctx, const void *d_raw, size_t len, 
     std::unique_lock<std::recursive_mutex> api_lock_;
     if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !d_out || !out_len || !level_ok(level) || (len && !d_raw)) return BZX_E_PARAM;
-    if (((uintptr_t)d_raw & 15u) || ((uintptr_t)d_out & 3u) || cap < 16) return BZX_E_PARAM;
+    if (((uintptr_t)d_raw & 15u) || ((uintptr_t)d_out & 3u) || cap < 16) {
+        ctx->err = "bzx_compress_device: d_raw must be 16-byte aligned, d_out 4-byte aligned, cap >= 16";
+        return BZX_E_PARAM;
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     uint32_t nblk = 0;
@@ -941,7 +966,10 @@ extern "C" int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, in
     std::unique_lock<std::recursive_mutex> api_lock_;
     if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !nblk_total || !d_bits || !level_ok(level) || world == 0 || rank >= world || (len && !d_raw)) return BZX_E_PARAM;
-    if ((uintptr_t)d_raw & 15u) return BZX_E_PARAM;
+    if ((uintptr_t)d_raw & 15u) {
+        ctx->err = "bzx_shard_prepare: d_raw must be 16-byte aligned";
+        return BZX_E_PARAM;
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     uint32_t nblk = 0;

@@ -39,11 +39,14 @@ def main():
            "units": "counter values are KiB (x1024 = bytes), summed over a kernel's dispatches and divided by the bench steps; "
                     "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> fetch "
                     "doubled; scattered 8-byte accesses are uncalibrated",
-           "kernels": kernels,
-           "bzx_bwt_kernel_hbm_bytes_per_step": kernels.get("bzx_bwt_kernel", {}).get("hbm_bytes_per_step")}
+           "kernels": kernels}
+    # per launch of the kernels bench.py's roofline object may name (one launch per step each)
+    for k in ("bzx_bsort_kernel", "bzx_bsplit_kernel", "bzx_bwt_kernel"):
+        if k in kernels:
+            out[k + "_hbm_bytes_per_launch"] = kernels[k]["hbm_bytes_per_step"] * steps // max(1, kernels[k]["dispatches"])
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
     json.dump(out, open(path, "w"), indent=1)
-    print("wrote", path, out["bzx_bwt_kernel_hbm_bytes_per_step"])
+    print("wrote", path, {k: v for k, v in out.items() if k.endswith("per_launch")})
 
 
 if __name__ == "__main__":
