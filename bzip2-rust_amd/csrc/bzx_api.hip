@@ -79,7 +79,9 @@ struct bzx_ctx {
                                      // BZX_SORTER=general in the environment selects the general sorter alone
     std::string err;
 
-    uint32_t cap_blocks = 0;   // per-block slab capacity
+    uint32_t cap_blocks = 0;   // block descriptor capacity (global block numbers)
+    uint32_t cap_slabs = 0;    // per-block slab capacity (owned blocks)
+    std::vector<void *> descs; // everything hipMalloc'ed for cap_blocks
     uint32_t n_slots = 0;      // per-workgroup scratch slots
     BzxBatch B;                // device pointers (by value into kernels)
     std::vector<void *> slabs; // everything hipMalloc'ed for cap_blocks
@@ -153,16 +155,29 @@ static void free_all(std::vector<void *> &v)
     v.clear();
 }
 
-// Per-block slabs for `nblk` blocks.
-static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk)
+// Block descriptors for `nblk` blocks (global block numbers) and per-block slabs for `nslab` of them (the blocks
+// this context owns: all of them, or every world-th one of a sharded run -- BZX_SLAB in bzx_device.h).
+static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk, uint32_t nslab = 0)
 {
-    if (nblk <= ctx->cap_blocks) return BZX_OK;
-    free_all(ctx->slabs);
-    ctx->cap_blocks = 0;
-    uint32_t cap = nblk < 16 ? 16 : nblk;
+    if (nslab == 0 || nslab > nblk) nslab = nblk;
     BzxBatch &B = ctx->B;
     int rc;
-    if ((rc = dev_alloc(ctx, ctx->slabs, &B.blk, cap))) return rc;
+    if (nblk > ctx->cap_blocks) {
+        free_all(ctx->descs);
+        ctx->cap_blocks = 0;
+        const uint32_t cap = nblk < 16 ? 16 : nblk;
+        if ((rc = dev_alloc(ctx, ctx->descs, &B.blk, cap))) return rc;
+        if ((rc = dev_alloc(ctx, ctx->descs, &B.plist, (size_t)cap))) return rc;
+        if ((rc = dev_alloc(ctx, ctx->descs, &B.redo_list, (size_t)cap))) return rc;
+        if (ctx->h_blk) (void)hipHostFree(ctx->h_blk);
+        ctx->h_blk = nullptr;
+        if (hipHostMalloc((void **)&ctx->h_blk, (size_t)cap * sizeof(BzxBlock), 0) != hipSuccess) return BZX_E_NOMEM;
+        ctx->cap_blocks = cap;
+    }
+    if (nslab <= ctx->cap_slabs) return BZX_OK;
+    free_all(ctx->slabs);
+    ctx->cap_slabs = 0;
+    const uint32_t cap = nslab < 16 ? 16 : nslab;
     if ((rc = dev_alloc(ctx, ctx->slabs, &ctx->d_in, (size_t)cap * BZX_BLK_STRIDE))) return rc;
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.bwt, (size_t)cap * BZX_BLK_STRIDE))) return rc;
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.rank, (size_t)cap * BZX_BLK_STRIDE))) return rc;
@@ -174,8 +189,6 @@ static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk)
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.selector, (size_t)cap * BZX_SEL_STRIDE))) return rc;
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.selector_mtf, (size_t)cap * BZX_SEL_STRIDE))) return rc;
     if ((rc = dev_alloc(ctx, ctx->slabs, &B.gbits, (size_t)cap * BZX_SEL_STRIDE))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->slabs, &B.plist, (size_t)cap))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->slabs, &B.redo_list, (size_t)cap))) return rc;
     if (ctx->use_bsort) {
         if ((rc = dev_alloc(ctx, ctx->slabs, &B.pk, (size_t)cap * BZX_PK_STRIDE))) return rc;
         if ((rc = dev_alloc(ctx, ctx->slabs, &B.rec_a, (size_t)cap * BZX_MAX_N))) return rc;
@@ -184,10 +197,7 @@ static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk)
         B.bk_cap = cap * BZX_BK_PER_BLOCK;
     }
     if ((rc = dev_alloc(ctx, ctx->slabs, &ctx->d_outbuf, (size_t)cap * (BZX_OUT_STRIDE / 4)))) return rc;
-    if (ctx->h_blk) (void)hipHostFree(ctx->h_blk);
-    ctx->h_blk = nullptr;
-    if (hipHostMalloc((void **)&ctx->h_blk, (size_t)cap * sizeof(BzxBlock), 0) != hipSuccess) return BZX_E_NOMEM;
-    ctx->cap_blocks = cap;
+    ctx->cap_slabs = cap;
     return BZX_OK;
 }
 
@@ -283,6 +293,7 @@ extern "C" void bzx_ctx_destroy(bzx_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     free_all(ctx->slabs);
+    free_all(ctx->descs);
     free_all(ctx->slot_allocs);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
@@ -792,7 +803,7 @@ static int split_on_device(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int l
     const size_t max_blocks_sz = (len + len / 4) / nmax + 2;
     if (max_blocks_sz > 0x7fffffffu) return BZX_E_PARAM;
     const uint32_t max_blocks = (uint32_t)max_blocks_sz;
-    int rc = ensure_blocks(ctx, max_blocks);
+    int rc = ensure_blocks(ctx, max_blocks, (max_blocks + own_step - 1) / own_step + 1);
     if (rc) return rc;
     BzxSplitWs ws;
     if ((rc = bzx_split_launch_boundaries(ctx, d_raw, len, level, max_blocks, &ws))) return rc;

@@ -220,9 +220,10 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
         const uint32_t b = B.blk_first + j_ * B.blk_step;
         const uint32_t n = B.blk[b].n;
         const uint8_t *__restrict__ T = BZX_BLOCK_PTR(B, B.blk[b]);
-        uint8_t *__restrict__ P = B.pk + (size_t)b * BZX_PK_STRIDE;
-        uint64_t *__restrict__ rec_a = B.rec_a + (size_t)b * BZX_MAX_N;
-        uint64_t *__restrict__ rec_b = B.rec_b + (size_t)b * BZX_MAX_N;
+        const size_t sb = BZX_SLAB(B, b);
+        uint8_t *__restrict__ P = B.pk + sb * BZX_PK_STRIDE;
+        uint64_t *__restrict__ rec_a = B.rec_a + sb * BZX_MAX_N;
+        uint64_t *__restrict__ rec_b = B.rec_b + sb * BZX_MAX_N;
 
         // ---- bytes in use -> dense symbol ids, bits per symbol, packed block
         DIAG_STAMP(96);
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(Bzx
     uint64_t nxt[BS_E];
     uint32_t n_cur = 0, st_cur = 0;
     if (it.cnt) {
-        const uint64_t *__restrict__ src = ((it.start >> 31) ? B.rec_b : B.rec_a) + (size_t)it.blk * BZX_MAX_N +
+        const uint64_t *__restrict__ src = ((it.start >> 31) ? B.rec_b : B.rec_a) + BZX_SLAB(B, it.blk) * BZX_MAX_N +
                                            (it.start & 0x7fffffffu);
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++) nxt[j] = j * SK_NT + tid0 < it.cnt ? src[j * SK_NT + tid0] : ~0ull;
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(Bzx
         uint32_t tid = tid_here(), lane = tid & 63u, wave = tid >> 6;
         const uint32_t b = it.blk, cnt = it.cnt;
         const uint32_t start = it.start & 0x7fffffffu, bits = it.dbits >> 16, depth0 = it.dbits & 0xFFFFu;
-        const uint8_t *__restrict__ P = B.pk + (size_t)b * BZX_PK_STRIDE;
+        const uint8_t *__restrict__ P = B.pk + BZX_SLAB(B, b) * BZX_PK_STRIDE;
         const uint32_t nbits = n_cur * bits;
         const bool skip = cnt == 0 || (st_cur & BZX_ST_REDO);      // empty, or the block goes to the general sorter anyway
         DIAG_STAMP(64);
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(Bzx
         }
         uint32_t n_nx = 0, st_nx = 0;
         if (nit.cnt) {
-            const uint64_t *__restrict__ src = ((nit.start >> 31) ? B.rec_b : B.rec_a) + (size_t)nit.blk * BZX_MAX_N +
+            const uint64_t *__restrict__ src = ((nit.start >> 31) ? B.rec_b : B.rec_a) + BZX_SLAB(B, nit.blk) * BZX_MAX_N +
                                                (nit.start & 0x7fffffffu);
 #pragma unroll
             for (uint32_t j = 0; j < BS_E; j++) nxt[j] = j * SK_NT + tid < nit.cnt ? src[j * SK_NT + tid] : ~0ull;
@@ -912,7 +913,7 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(Bzx
         if (fail) {
             if (tid == 0) block_redo(B, b);
         } else {
-            uint8_t *__restrict__ L = B.bwt + (size_t)b * BZX_BLK_STRIDE + start;
+            uint8_t *__restrict__ L = B.bwt + BZX_SLAB(B, b) * BZX_BLK_STRIDE + start;
 #pragma unroll
             for (uint32_t j = 0; j < BS_E; j++) {
                 const uint32_t p = j * SK_NT + tid;

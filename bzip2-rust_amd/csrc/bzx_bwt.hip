@@ -979,7 +979,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
 
         const uint32_t n = B.blk[b].n;
         const uint8_t *__restrict__ T = BZX_BLOCK_PTR(B, B.blk[b]);
-        uint8_t *__restrict__ L = B.bwt + (size_t)b * BZX_BLK_STRIDE;
+        uint8_t *__restrict__ L = B.bwt + BZX_SLAB(B, b) * BZX_BLK_STRIDE;
         unsigned long long t_blk0 = 0;
         if (DBG_ON && tid == 0) t_last = t_blk0 = wall_clock64();
 

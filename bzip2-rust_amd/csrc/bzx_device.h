@@ -125,5 +125,11 @@ struct BzxSplitWs {
 };
 
 
+// Slab of block b.  Block DESCRIPTORS (B.blk, plist, redo_list) are indexed by the global block number; the per-block
+// slabs (bwt, rank, mtfv, tables, packed block, records, RLE1 bytes) exist only for the blocks a launch owns
+// (round-robin sharding over GPUs: b = blk_first + j * blk_step owns slab j), so a rank of an 8-GPU job holds 1/8
+// of them.
+#define BZX_SLAB(B, b) ((size_t)(((b) - (B).blk_first) / (B).blk_step))
+
 // Block bytes of a descriptor.
 #define BZX_BLOCK_PTR(B, d) (((d).in_off & BZX_IN_RAW) ? ((B).raw + ((d).in_off & ~BZX_IN_RAW)) : ((B).in + (d).in_off))

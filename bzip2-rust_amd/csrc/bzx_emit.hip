@@ -101,10 +101,10 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
         if (B.dbg && tid == 0) t_last = wall_clock64();
         const BzxBlock d = B.blk[b];
         const uint32_t alpha = d.n_in_use + 2, n_mtf = d.n_mtf, n_sel = d.n_selectors, n_groups = d.n_groups;
-        const uint16_t *__restrict__ V = B.mtfv + (size_t)b * BZX_BLK_STRIDE;
-        const uint8_t *__restrict__ SEL = B.selector + (size_t)b * BZX_SEL_STRIDE;
-        const uint8_t *__restrict__ SELM = B.selector_mtf + (size_t)b * BZX_SEL_STRIDE;
-        const uint16_t *__restrict__ GB = B.gbits + (size_t)b * BZX_SEL_STRIDE;
+        const uint16_t *__restrict__ V = B.mtfv + BZX_SLAB(B, b) * BZX_BLK_STRIDE;
+        const uint8_t *__restrict__ SEL = B.selector + BZX_SLAB(B, b) * BZX_SEL_STRIDE;
+        const uint8_t *__restrict__ SELM = B.selector_mtf + BZX_SLAB(B, b) * BZX_SEL_STRIDE;
+        const uint16_t *__restrict__ GB = B.gbits + BZX_SLAB(B, b) * BZX_SEL_STRIDE;
         uint32_t *out = B.out;
 
         // final stream position, or (sharded runs) the same bit phase inside this rank's packed buffer
@@ -118,9 +118,9 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
         for (uint32_t i = tid; i < 6 * 260; i += EMIT_NT) {
             const uint32_t t = i / 260, v = i % 260;
             if (v < BZX_MAX_ALPHA + 2) {
-                e_len[t][v] = B.len[(size_t)b * 6 * 260 + i];
-                e_code[t][v] = B.code[(size_t)b * 6 * 260 + i];
-                e_cl[t][v] = B.code[(size_t)b * 6 * 260 + i] | ((uint32_t)B.len[(size_t)b * 6 * 260 + i] << 24);
+                e_len[t][v] = B.len[BZX_SLAB(B, b) * 6 * 260 + i];
+                e_code[t][v] = B.code[BZX_SLAB(B, b) * 6 * 260 + i];
+                e_cl[t][v] = B.code[BZX_SLAB(B, b) * 6 * 260 + i] | ((uint32_t)B.len[BZX_SLAB(B, b) * 6 * 260 + i] << 24);
             }
         }
         __syncthreads();
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_emit_kernel(BzxBatch B)
             for (uint32_t i = 0; i < 16; i++) {
                 uint32_t wv = 0;
                 for (uint32_t j = 0; j < 16; j++)
-                    if (B.in_use[(size_t)b * 256 + i * 16 + j]) wv |= 0x8000u >> j;
+                    if (B.in_use[BZX_SLAB(B, b) * 256 + i * 16 + j]) wv |= 0x8000u >> j;
                 words[i] = wv;
                 if (wv) l1 |= 0x8000u >> i;
             }

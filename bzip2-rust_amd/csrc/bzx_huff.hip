@@ -137,14 +137,14 @@ __global__ __launch_bounds__(HUF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         if (B.dbg && tid == 0) t_last = wall_clock64();
         const uint32_t n_mtf = B.blk[b].n_mtf;
         const uint32_t alpha = B.blk[b].n_in_use + 2;
-        const uint16_t *__restrict__ V = B.mtfv + (size_t)b * BZX_BLK_STRIDE;
-        uint8_t *__restrict__ SEL = B.selector + (size_t)b * BZX_SEL_STRIDE;
-        uint8_t *__restrict__ SELM = B.selector_mtf + (size_t)b * BZX_SEL_STRIDE;
-        uint16_t *__restrict__ GB = B.gbits + (size_t)b * BZX_SEL_STRIDE;
+        const uint16_t *__restrict__ V = B.mtfv + BZX_SLAB(B, b) * BZX_BLK_STRIDE;
+        uint8_t *__restrict__ SEL = B.selector + BZX_SLAB(B, b) * BZX_SEL_STRIDE;
+        uint8_t *__restrict__ SELM = B.selector_mtf + BZX_SLAB(B, b) * BZX_SEL_STRIDE;
+        uint16_t *__restrict__ GB = B.gbits + BZX_SLAB(B, b) * BZX_SEL_STRIDE;
         const uint32_t n_sel = (n_mtf + BZX_G_SIZE - 1) / BZX_G_SIZE;
         const uint32_t n_groups = n_mtf < 200 ? 2u : n_mtf < 600 ? 3u : n_mtf < 1200 ? 4u : n_mtf < 2400 ? 5u : 6u;
 
-        for (uint32_t i = tid; i < BZX_MAX_ALPHA + 2; i += HUF_NT) h_freq[i] = i < alpha ? B.freq[(size_t)b * 260 + i] : 0u;
+        for (uint32_t i = tid; i < BZX_MAX_ALPHA + 2; i += HUF_NT) h_freq[i] = i < alpha ? B.freq[BZX_SLAB(B, b) * 260 + i] : 0u;
         if (tid < 4) h_acc[tid] = 0;
         __syncthreads();
 
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(HUF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         for (uint32_t i = tid; i < 6 * 260; i += HUF_NT) {
             const uint32_t t = i / 260, v = i % 260;
             const bool live = t < n_groups && v < alpha;
-            B.len[(size_t)b * 6 * 260 + i] = live ? h_len[t][v] : (uint8_t)0;
-            B.code[(size_t)b * 6 * 260 + i] = live ? h_code[t][v] : 0u;
+            B.len[BZX_SLAB(B, b) * 6 * 260 + i] = live ? h_len[t][v] : (uint8_t)0;
+            B.code[BZX_SLAB(B, b) * 6 * 260 + i] = live ? h_code[t][v] : 0u;
         }
         for (uint32_t v = tid; v < BZX_MAX_ALPHA + 2; v += HUF_NT) {
             h_lenAB[v] = make_uint2((uint32_t)h_len[0][v] | ((uint32_t)h_len[1][v] << 10) | ((uint32_t)h_len[2][v] << 20),
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(HUF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             uint32_t map_words = 0;
             for (uint32_t i = 0; i < 16; i++) {
                 uint32_t any = 0;
-                for (uint32_t j = 0; j < 16; j++) any |= B.in_use[(size_t)b * 256 + i * 16 + j];
+                for (uint32_t j = 0; j < 16; j++) any |= B.in_use[BZX_SLAB(B, b) * 256 + i * 16 + j];
                 map_words += any ? 1u : 0u;
             }
             const uint32_t map_bits = 16 + 16 * map_words;

@@ -235,9 +235,9 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         const uint32_t b = B.blk_first + j_ * B.blk_step;
 
         const uint32_t n = B.blk[b].n;
-        const uint8_t *__restrict__ L = B.bwt + (size_t)b * BZX_BLK_STRIDE;
-        uint8_t *__restrict__ R = B.rank + (size_t)b * BZX_BLK_STRIDE;
-        uint16_t *__restrict__ V = B.mtfv + (size_t)b * BZX_BLK_STRIDE;
+        const uint8_t *__restrict__ L = B.bwt + BZX_SLAB(B, b) * BZX_BLK_STRIDE;
+        uint8_t *__restrict__ R = B.rank + BZX_SLAB(B, b) * BZX_BLK_STRIDE;
+        uint16_t *__restrict__ V = B.mtfv + BZX_SLAB(B, b) * BZX_BLK_STRIDE;
 
         if (B.dbg && tid == 0) t_last = wall_clock64();
         // ---- 1. bytes in use -> dense ids (rle2_mtf.rs:26-45)
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
             const uint32_t ex = bzx_block_excl_sum<MTF_NT>(flag, m_scratch, n_in_use);
             if (tid < 256) {
                 m_seq[tid] = (uint8_t)ex;
-                B.in_use[(size_t)b * 256 + tid] = (uint8_t)flag;
+                B.in_use[BZX_SLAB(B, b) * 256 + tid] = (uint8_t)flag;
             }
         }
         __syncthreads();
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
             B.blk[b].n_in_use = n_in_use;
         }
         __syncthreads();
-        for (uint32_t i = tid; i < 260; i += MTF_NT) B.freq[(size_t)b * 260 + i] = i < BZX_MAX_ALPHA ? m_freq[i] : 0u;
+        for (uint32_t i = tid; i < 260; i += MTF_NT) B.freq[BZX_SLAB(B, b) * 260 + i] = i < BZX_MAX_ALPHA ? m_freq[i] : 0u;
         __syncthreads();
     }
 }

@@ -578,7 +578,7 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_scatter_kernel(const uint8_t *__
             uint32_t kb = lo;
             uint64_t next_raw = ws.blk_raw[kb + 1];
             uint64_t f0 = ws.blk_f[kb];
-            uint8_t *dst = slabs + (size_t)kb * BZX_BLK_STRIDE;
+            uint8_t *dst = slabs + (size_t)(kb / own_step) * BZX_BLK_STRIDE;      // (slab of an owned block: its local index)
             uint64_t f = ws.tile_off[tile] + ti.f_excl;
             for (int i = 0; i < RL_BYTES; i++) {
                 if ((uint32_t)i < ti.t.nvalid) {
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_scatter_kernel(const uint8_t *__
                         kb++;
                         next_raw = ws.blk_raw[kb + 1];
                         f0 = ws.blk_f[kb];
-                        dst = slabs + (size_t)kb * BZX_BLK_STRIDE;
+                        dst = slabs + (size_t)(kb / own_step) * BZX_BLK_STRIDE;
                     }
                     const uint32_t e = (uint32_t)(ti.e_bits >> (2 * i)) & 3u;
                     if (e && ((kb % own_step) != own_first || ws.blk_plain[kb])) {
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_scatter_kernel(const uint8_t *__
         __syncthreads();
     }
     for (uint32_t b = blockIdx.x * RL_NT + threadIdx.x; b < nblk; b += gridDim.x * RL_NT) {
-        blk[b].in_off = (ws.blk_plain[b] || all_plain) ? (BZX_IN_RAW | ws.blk_raw[b]) : (uint64_t)b * BZX_BLK_STRIDE;
+        blk[b].in_off = (ws.blk_plain[b] || all_plain) ? (BZX_IN_RAW | ws.blk_raw[b]) : (uint64_t)(b / own_step) * BZX_BLK_STRIDE;
         blk[b].n = (uint32_t)(ws.blk_f[b + 1] - ws.blk_f[b]);
         blk[b].status = 0;
     }
