@@ -11,6 +11,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -32,6 +33,15 @@ int bzx_split_launch_boundaries(struct bzx_ctx *ctx, const uint8_t *d_raw, size_
                                 BzxSplitWs *ws_out);
 void bzx_split_launch_scatter(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, const BzxSplitWs &ws,
                               uint32_t nblk, uint8_t *d_slabs, BzxBlock *d_blk, uint32_t own_first, uint32_t own_step);
+void bzx_launch_dc_scan(const uint8_t *z, uint64_t nbytes, uint64_t *found, uint32_t *n_found, uint32_t cap, uint32_t grid,
+                        hipStream_t stream);
+void bzx_launch_dc_decode(const BzxBatch &B, const uint8_t *z, uint64_t nbytes, const uint64_t *starts, uint32_t max_n,
+                          hipStream_t stream);
+void bzx_launch_dc_ibwt(const BzxBatch &B, uint8_t *img_slabs, hipStream_t stream);
+void bzx_launch_dc_expand(const BzxBatch &B, const uint8_t *img_slabs, const uint64_t *off, uint8_t *out, uint64_t cap,
+                          hipStream_t stream);
+void bzx_launch_block_crcs(bzx_ctx *ctx, const uint8_t *d_raw, const uint64_t *d_bounds, uint32_t *d_nblk, BzxBlock *d_blk,
+                           uint32_t nblk);
 uint32_t bzx_bwt_max_blocks_per_cu();
 uint32_t bzx_bsort_blocks_per_cu();
 void bzx_launch_bits_export(const BzxBatch &B, long long *bits, hipStream_t stream);
@@ -130,6 +140,7 @@ extern "C" const char *bzx_strerror(int code)
     case BZX_E_OUTBUF: return "output buffer too small";
     case BZX_E_HIP: return "HIP runtime error";
     case BZX_E_STATE: return "bad call sequence";
+    case BZX_E_DATA: return "damaged or invalid bzip2 data";
     default: return "unknown error";
     }
 }
@@ -1128,6 +1139,195 @@ extern "C" int bzx_shard_assemble_rank(bzx_ctx *ctx, const void *d_packed_r, uin
     bzx_launch_unpack(B, (const uint32_t *)d_packed_r, r, world, nown, grid_for(ctx, nown, 4), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return BZX_OK;
+}
+
+// ---- decompression (include/bzx.h: bzx_decompress_*; kernels in bzx_decomp.hip) ----------------------------------
+#define DC_MAX_FOUND 262144u
+
+extern "C" int bzx_decompress_device(bzx_ctx *ctx, const void *d_bz2, size_t len, void *d_out, size_t cap, size_t *out_len)
+{
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
+    if (!ctx || !d_bz2 || !out_len || (cap && !d_out) || ((uintptr_t)d_out & 15u)) return BZX_E_PARAM;
+    if (!ctx->use_bsort) {
+        ctx->err = "decompression needs the bucket sorter's buffers (BZX_SORTER=general is set)";
+        return BZX_E_STATE;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *out_len = 0;
+    const uint8_t *z = (const uint8_t *)d_bz2;
+    uint8_t head[4] = {0, 0, 0, 0};
+    if (len < 14) {
+        ctx->err = "shorter than the smallest bzip2 stream";
+        return BZX_E_DATA;
+    }
+    HIP_TRY(ctx, hipMemcpy(head, z, 4, hipMemcpyDeviceToHost));
+    if (head[0] != 'B' || head[1] != 'Z' || head[2] != 'h' || head[3] < '1' || head[3] > '9') {
+        ctx->err = "no BZh1..BZh9 header";
+        return BZX_E_DATA;
+    }
+    const uint32_t max_n = 100000u * (uint32_t)(head[3] - '0');
+    // ---- scan for block / end-of-stream magics at every bit offset
+    void *scratch = nullptr;
+    int rc = bzx_ctx_split_scratch(ctx, (size_t)DC_MAX_FOUND * 8 * 3 + 4096, &scratch);
+    if (rc) return rc;
+    uint64_t *d_found = (uint64_t *)scratch;
+    uint64_t *d_starts = d_found + DC_MAX_FOUND;
+    uint64_t *d_off = d_starts + DC_MAX_FOUND;
+    uint32_t *d_nfound = (uint32_t *)(d_off + DC_MAX_FOUND);
+    HIP_TRY(ctx, hipMemsetAsync(d_nfound, 0, 64, ctx->stream));
+    bzx_launch_dc_scan(z, len, d_found, d_nfound, DC_MAX_FOUND, (uint32_t)ctx->n_cu * 8, ctx->stream);
+    uint32_t nfound = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&nfound, d_nfound, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (nfound > DC_MAX_FOUND) {
+        ctx->err = "too many block-magic candidates";
+        return BZX_E_DATA;
+    }
+    std::vector<uint64_t> found, starts;
+    try {
+        found.resize(nfound);
+        if (nfound) HIP_TRY(ctx, hipMemcpy(found.data(), d_found, (size_t)nfound * 8, hipMemcpyDeviceToHost));
+        std::sort(found.begin(), found.end());
+        for (uint64_t f : found)
+            if (!(f & 1u)) starts.push_back(f >> 1);
+    } catch (const std::bad_alloc &) {
+        return BZX_E_NOMEM;
+    }
+    auto is_eos = [&](uint64_t bit) { return std::binary_search(found.begin(), found.end(), (bit << 1) | 1u); };
+    // ---- decode every candidate; keep the chain that starts at bit 32 (a chance match of the magic inside compressed
+    // data does not continue the chain: drop it and decode again without it)
+    uint64_t end_bit = 32;
+    uint32_t nblk = 0;
+    for (int attempt = 0;; attempt++) {
+        nblk = (uint32_t)starts.size();
+        end_bit = 32;
+        if (nblk == 0) break;
+        if ((rc = ensure_blocks(ctx, nblk))) return rc;
+        BzxBatch &B = ctx->B;
+        B.nblk = nblk;
+        B.blk_first = 0;
+        B.blk_step = 1;
+        HIP_TRY(ctx, hipMemcpyAsync(d_starts, starts.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, ctx->stream));
+        bzx_launch_dc_decode(B, z, len, d_starts, max_n, ctx->stream);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_blk, B.blk, (size_t)nblk * sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<uint64_t> chain;
+        bool clean = true;
+        uint32_t i = 0;
+        while (i < nblk) {
+            if (starts[i] != end_bit) {             // not where the previous block ended: a chance match
+                clean = false;
+                i++;
+                continue;
+            }
+            if (ctx->h_blk[i].status) {
+                ctx->err = "damaged block in the bzip2 stream";
+                return BZX_E_DATA;
+            }
+            chain.push_back(starts[i]);
+            end_bit = ctx->h_blk[i].bits;
+            i++;
+        }
+        if (clean) break;
+        if (attempt >= 3) {
+            ctx->err = "cannot follow the chain of blocks";
+            return BZX_E_DATA;
+        }
+        starts.swap(chain);
+    }
+    if (!is_eos(end_bit)) {
+        ctx->err = "blocks do not end at an end-of-stream marker";
+        return BZX_E_DATA;
+    }
+    uint8_t foot[16] = {0};
+    {
+        const size_t fb = (size_t)((end_bit + 48) >> 3);
+        const size_t nfb = len - fb < 5 ? len - fb : 5;
+        if ((end_bit + 80 + 7) / 8 > len) {
+            ctx->err = "truncated after the end-of-stream marker";
+            return BZX_E_DATA;
+        }
+        HIP_TRY(ctx, hipMemcpy(foot, z + fb, nfb, hipMemcpyDeviceToHost));
+    }
+    uint64_t fv = 0;
+    for (int i = 0; i < 5; i++) fv = (fv << 8) | foot[i];
+    const uint32_t stream_crc = (uint32_t)((fv << ((end_bit + 48) & 7u)) >> 8);
+    uint64_t total = 0;
+    uint32_t comb = 0;
+    if (nblk) {
+        BzxBatch &B = ctx->B;
+        // ---- inverse BWT, expanded sizes, offsets
+        bzx_launch_dc_ibwt(B, ctx->d_in, ctx->stream);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_blk, B.blk, (size_t)nblk * sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<uint64_t> off;
+        try {
+            off.resize((size_t)nblk + 1);
+        } catch (const std::bad_alloc &) {
+            return BZX_E_NOMEM;
+        }
+        for (uint32_t b = 0; b < nblk; b++) {
+            if (ctx->h_blk[b].status) {
+                ctx->err = "damaged block in the bzip2 stream (inverse BWT)";
+                return BZX_E_DATA;
+            }
+            off[b] = total;
+            total += ctx->h_blk[b].pack_word;
+            comb = ((comb << 1) | (comb >> 31)) ^ ctx->h_blk[b].crc;       // stored CRCs (crc.rs:25-27)
+        }
+        off[nblk] = total;
+        *out_len = (size_t)total;
+        if (total > cap) {
+            ctx->err = "output buffer too small for the decompressed data";
+            return BZX_E_OUTBUF;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(d_off, off.data(), ((size_t)nblk + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        bzx_launch_dc_expand(B, ctx->d_in, d_off, (uint8_t *)d_out, total, ctx->stream);
+        // ---- block CRCs of the output (the compressor's CRC kernel), against the stored ones
+        std::vector<uint32_t> stored(nblk);
+        for (uint32_t b = 0; b < nblk; b++) stored[b] = ctx->h_blk[b].crc;
+        HIP_TRY(ctx, hipMemcpyAsync(d_nfound, &nblk, 4, hipMemcpyHostToDevice, ctx->stream));
+        bzx_launch_block_crcs(ctx, (const uint8_t *)d_out, d_off, d_nfound, B.blk, nblk);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_blk, B.blk, (size_t)nblk * sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipGetLastError());
+        for (uint32_t b = 0; b < nblk; b++) {
+            if (ctx->h_blk[b].crc != stored[b]) {
+                ctx->err = "block CRC mismatch in block " + std::to_string(b);
+                return BZX_E_DATA;
+            }
+        }
+    }
+    if (comb != stream_crc) {
+        ctx->err = "combined CRC mismatch";
+        return BZX_E_DATA;
+    }
+    *out_len = (size_t)total;
+    ctx->stats.nblk = nblk;
+    ctx->stats.raw_bytes = total;
+    return BZX_OK;
+}
+
+extern "C" int bzx_decompress_buffer(bzx_ctx *ctx, const uint8_t *bz2, size_t len, uint8_t *out, size_t cap, size_t *out_len)
+{
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
+    if (!ctx || !bz2 || !out_len || (cap && !out)) return BZX_E_PARAM;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *d_z = nullptr, *d_o = nullptr;
+    if (hipMalloc(&d_z, len + 64) != hipSuccess) return BZX_E_NOMEM;
+    if (hipMalloc(&d_o, cap + 64) != hipSuccess) {
+        (void)hipFree(d_z);
+        return BZX_E_NOMEM;
+    }
+    int rc = hipMemcpyAsync(d_z, bz2, len, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? BZX_OK : BZX_E_HIP;
+    if (!rc) rc = bzx_decompress_device(ctx, d_z, len, d_o, cap, out_len);
+    if (!rc && *out_len && hipMemcpy(out, d_o, *out_len, hipMemcpyDeviceToHost) != hipSuccess) rc = BZX_E_HIP;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_z);
+    (void)hipFree(d_o);
+    return rc;
 }
 
 // RLE1Block::new(source, block_size) + Iterator::next (rle1.rs:49-85,245-263) for a source that arrives in pieces:

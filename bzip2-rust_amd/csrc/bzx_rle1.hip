@@ -20,6 +20,7 @@
 //   E  per block: CRC of its raw range: per-lane table CRC of a chunk from a zero register,
 //      combined with x^(8*len) mod P multiplications (GF(2) polynomial arithmetic).
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include "bzx_device.h"
 #include "bzx_wg.h"
 
@@ -802,3 +803,16 @@ void bzx_split_launch_scatter(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, co
 }
 
 uint32_t *bzx_split_nblk_ptr(const BzxSplitWs &ws) { return ws.nblk; }
+
+// CRC-32/BZIP2 of nblk consecutive byte ranges [bounds[b], bounds[b+1]) of d_raw into blk[b].crc (the decompressor
+// checks its output with the compressor's kernel).  d_nblk: device word holding nblk.
+void bzx_launch_block_crcs(bzx_ctx *ctx, const uint8_t *d_raw, const uint64_t *d_bounds, uint32_t *d_nblk, BzxBlock *d_blk,
+                           uint32_t nblk)
+{
+    BzxSplitWs ws;
+    memset(&ws, 0, sizeof(ws));
+    ws.blk_raw = const_cast<uint64_t *>(d_bounds);
+    ws.nblk = d_nblk;
+    const uint32_t cgrid = nblk < (uint32_t)bzx_ctx_ncu(ctx) ? (nblk ? nblk : 1) : (uint32_t)bzx_ctx_ncu(ctx);
+    hipLaunchKernelGGL(bzx_rl_crc_kernel, dim3(cgrid), dim3(CRC_NT), 0, bzx_ctx_stream(ctx), d_raw, ws, d_blk, 0u, 1u);
+}

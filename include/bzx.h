@@ -35,6 +35,7 @@ extern "C" {
 #define BZX_E_OUTBUF (-4)     /* output buffer too small */
 #define BZX_E_HIP (-5)        /* HIP runtime error during a call (see bzx_last_error) */
 #define BZX_E_STATE (-6)      /* call sequence error (stream API) */
+#define BZX_E_DATA (-7)       /* decompression: not a bzip2 stream, damaged data, or a CRC mismatch (see bzx_last_error) */
 
 #define BZX_MAX_BLOCK 900000u
 
@@ -165,6 +166,17 @@ int bzx_cstream_feed(bzx_cstream *s, const uint8_t *raw, size_t len, int final, 
 void bzx_cstream_end(bzx_cstream *s);
 void *bzx_host_alloc(size_t bytes);     /* page-locked host memory (NULL on failure) */
 void bzx_host_free(void *p);
+
+/*
+ * Decompression on the device (replaces decompress(), decompress.rs:38-404 minus file I/O; bwt_decode
+ * bwt_sort.rs:91-130, rle2_mtf_decode_fast rle2_mtf.rs:191-287, rle1_decode rle1.rs:267-316): one .bz2 stream ->
+ * raw bytes; every block CRC and the combined CRC are verified (a mismatch is BZX_E_DATA, unlike the reference, which
+ * logs it and continues, decompress.rs:379-386).  The blocks of the stream are decoded side by side.
+ * _device: d_bz2 / d_out are DEVICE pointers (d_out 16-byte aligned); _buffer: host pointers.
+ * BZX_E_OUTBUF: *out_len = bytes needed.  Bytes after the end-of-stream marker are ignored.
+ */
+int bzx_decompress_device(bzx_ctx *ctx, const void *d_bz2, size_t len, void *d_out, size_t cap, size_t *out_len);
+int bzx_decompress_buffer(bzx_ctx *ctx, const uint8_t *bz2, size_t len, uint8_t *out, size_t cap, size_t *out_len);
 
 /* Per-call telemetry of the last bzx_compress_device/_buffer/_blocks call. */
 typedef struct {

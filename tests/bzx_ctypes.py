@@ -205,6 +205,21 @@ class BzxLib:
             if fin:
                 return out
 
+    def decompress_buffer(self, z: bytes, cap=None):
+        """bzx_decompress_buffer: one .bz2 stream -> raw bytes (block and combined CRCs verified on the device)."""
+        L = self.lib
+        L.bzx_decompress_buffer.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        cap = cap if cap is not None else max(1 << 16, len(z) * 8)
+        while True:
+            out = C.create_string_buffer(cap)
+            ol = C.c_size_t()
+            rc = L.bzx_decompress_buffer(self.ctx, z, len(z), out, cap, C.byref(ol))
+            if rc == -4 and ol.value > cap:         # BZX_E_OUTBUF: the needed size is reported
+                cap = ol.value
+                continue
+            self._check(rc)
+            return out.raw[:ol.value]
+
     def stats(self):
         st = BzxStats()
         self._check(self.lib.bzx_get_stats(self.ctx, C.byref(st)))

@@ -90,7 +90,8 @@ void launch(void (*tramp)(void *), void *args, dim3 grid, dim3 block)
         fibers.resize(nthreads);
         for (size_t i = old; i < nthreads; i++) fibers[i].stack = (char *)malloc(STACK);
     }
-    for (unsigned b = 0; b < grid.x; b++) {
+    for (unsigned bb = 0; bb < grid.x * grid.y; bb++) {
+        const unsigned b = bb % grid.x, by = bb / grid.x;      // 2-D grids: x fastest
         wave_arrived.assign(nw, 0);
         wave_gen.assign(nw, 0);
         slots.assign((size_t)nw * 64, 0);
@@ -116,7 +117,7 @@ void launch(void (*tramp)(void *), void *args, dim3 grid, dim3 block)
                 f.state = 0;
                 cur = t;
                 threadIdx.x = t; threadIdx.y = 0; threadIdx.z = 0;
-                blockIdx.x = b; blockIdx.y = 0; blockIdx.z = 0;
+                blockIdx.x = b; blockIdx.y = by; blockIdx.z = 0;
                 swapcontext(&sched_ctx, &f.ctx);
                 progressed++;
                 if (f.state == 3) done++;

@@ -109,3 +109,20 @@ def test_emu_chunked_stream_and_chunked_split(emu, oracle):
         assert emu.cstream_compress(data, level, chunk) == bz2.compress(data, level), (len(data), chunk)
     for data, level, chunk in cases[1:5]:
         assert emu.split_rle1_chunks(data, level, chunk) == oracle.split_rle1(data, level), (len(data), chunk)
+
+
+def test_emu_decompress(emu, oracle):
+    """bzx_decompress_buffer (decompress.rs:38-404): libbz2-made streams come back as the input; damage is reported."""
+    from bzx_ctypes import BzxError
+    rnd = random.Random(9)
+    cases = [(b"", 9), (b"xyz", 9), (b"Making a silly test.", 9), (oracle.synthtext(40000), 1), (rnd.randbytes(30000), 1),
+             (b"\0" * 70000 + b"ab" * 300 + b"\xff" * 1000, 1), (oracle.synthtext(250000), 1),
+             (bytes(rnd.choice(b"ab") for _ in range(20000)), 9)]
+    for data, level in cases:
+        assert emu.decompress_buffer(bz2.compress(data, level)) == data, (len(data), level)
+    z = bytearray(bz2.compress(oracle.synthtext(30000), 1))
+    z[len(z) // 2] ^= 0x10
+    with pytest.raises(BzxError):
+        emu.decompress_buffer(bytes(z))
+    with pytest.raises(BzxError):
+        emu.decompress_buffer(bz2.compress(oracle.synthtext(30000), 1)[:-7])

@@ -238,6 +238,36 @@ def test_chunked_split(bzx, oracle):
         assert bzx.split_rle1_chunks(runs, 9, chunk) == want, chunk
 
 
+def test_decompress_libbz2_streams_and_own(bzx, oracle):
+    """Device decompression (decompress.rs:38-404): streams made by libbz2 and by the device itself
+    decode to the input; block CRCs and the combined CRC are checked on the way; damaged streams are refused."""
+    from bzx_ctypes import BzxError
+    from gen_golden import make_input
+    for name, blk in _cases(oracle):
+        for level in (1, 9):
+            assert bzx.decompress_buffer(bz2.compress(blk, level), cap=len(blk) + 16) == blk, (name, level)
+    for name in ("empty", "config1_text_1MiB_l1", "random_3MiB_l9", "zeros_2MiB_l9", "runs_mixed_l9", "allbytes_l1"):
+        g = GOLDEN["streams"][name]
+        data = make_input(oracle, g["input"])
+        assert bzx.decompress_buffer(bz2.compress(data, g["level"]), cap=len(data) + 16) == data, name
+    # the device's own output, hundreds of blocks; and the size is reported when the buffer is too small
+    big = oracle.synthtext(200 << 20)
+    z = bzx.compress_buffer(big, 9)
+    assert bzx.decompress_buffer(z, cap=1 << 20) == big
+    zeros = b"\0" * (100 << 20) + b"x"
+    assert bzx.decompress_buffer(bzx.compress_buffer(zeros, 9), cap=len(zeros)) == zeros
+    z = bytearray(bz2.compress(oracle.synthtext(3_000_000), 9))
+    for damage in (len(z) // 2, 12, len(z) - 3):
+        bad = bytearray(z)
+        bad[damage] ^= 0x04
+        with pytest.raises(BzxError):
+            bzx.decompress_buffer(bytes(bad))
+    with pytest.raises(BzxError):
+        bzx.decompress_buffer(bytes(z[:-9]))
+    with pytest.raises(BzxError):
+        bzx.decompress_buffer(b"not a bzip2 stream at all")
+
+
 def test_large_roundtrip_properties(bzx, oracle):
     """Size-independent properties at a multi-hundred-block size (BASELINE configs[2] shape, scaled to keep the
     test short): libbz2 decodes the device stream back to the input; block count and framing are right; the first
