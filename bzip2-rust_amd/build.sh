@@ -16,3 +16,6 @@ if [ "$1" = "diag" ]; then
 fi
 $HIPCC $FLAGS $SRCS -o libbzx.so "$@"
 echo "built $(pwd)/libbzx.so"
+# thin command line over the C ABI; host code only
+g++ -O2 -std=c++17 -Wall ../tools/bzx.cpp -I ../include -L . -lbzx -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib -o bzx
+echo "built $(pwd)/bzx"

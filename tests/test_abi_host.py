@@ -74,3 +74,21 @@ def test_stream_assembler_matches_libbz2(oracle):
         assert out == bz2.compress(data, level)
     s = C.c_void_p()
     assert lib.bzx_stream_begin(0, C.byref(s)) == -2    # BZX_E_PARAM
+
+
+def test_command_line_tool_builds_and_refuses_to_run_without_a_device():
+    """tools/bzx.cpp is host glue over the C ABI: it must exist after build() and, like the library,
+    it has no CPU path."""
+    import subprocess
+    exe = os.path.join(ROOT, "bzip2-rust_amd", "bzx")
+    if not os.path.exists(exe):
+        subprocess.check_call(["bash", os.path.join(ROOT, "bzip2-rust_amd", "build.sh")])
+    assert b"bzx" in subprocess.run([exe, "--version"], stdout=subprocess.PIPE, check=True).stdout
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        r = subprocess.run([exe, "-c"], input=b"abc", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 2 and b"no CPU path" in r.stderr

@@ -268,6 +268,32 @@ def test_decompress_libbz2_streams_and_own(bzx, oracle):
         bzx.decompress_buffer(b"not a bzip2 stream at all")
 
 
+def test_command_line_tool(oracle, tmp_path):
+    """bzx (tools/bzx.cpp; reference src/tools/cli.rs:113-303, main.rs:30-34): -z/-d/-t, levels, -c, -k, -f, stdin/stdout;
+    the files it writes are libbz2's, byte for byte."""
+    import subprocess
+    from bzx_ctypes import ROOT
+    exe = os.path.join(ROOT, "bzip2-rust_amd", "bzx")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    data = oracle.synthtext(2_500_000) + b"\0" * 100_000
+    p = tmp_path / "a.txt"
+    p.write_bytes(data)
+    subprocess.check_call([exe, "-k", "-5", str(p)])
+    assert (tmp_path / "a.txt.bz2").read_bytes() == bz2.compress(data, 5) and p.exists()
+    assert subprocess.run([exe, str(p)]).returncode != 0                        # output exists, no -f
+    subprocess.check_call([exe, "-f", "--best", str(p)])
+    assert (tmp_path / "a.txt.bz2").read_bytes() == bz2.compress(data, 9) and not p.exists()
+    subprocess.check_call([exe, "-t", str(tmp_path / "a.txt.bz2")])
+    subprocess.check_call([exe, "-d", str(tmp_path / "a.txt.bz2")])
+    assert p.read_bytes() == data and not (tmp_path / "a.txt.bz2").exists()
+    z = subprocess.run([exe, "-c", "-1"], input=data, stdout=subprocess.PIPE, check=True).stdout
+    assert z == bz2.compress(data, 1)
+    assert subprocess.run([exe, "-dc"], input=z, stdout=subprocess.PIPE, check=True).stdout == data
+    bad = bytearray(z)
+    bad[len(bad) // 3] ^= 1
+    assert subprocess.run([exe, "-t"], input=bytes(bad), stderr=subprocess.PIPE).returncode != 0
+
+
 def test_large_roundtrip_properties(bzx, oracle):
     """Size-independent properties at a multi-hundred-block size (BASELINE configs[2] shape, scaled to keep the
     test short): libbz2 decodes the device stream back to the input; block count and framing are right; the first
