@@ -180,6 +180,7 @@ static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk, uint32_t nslab = 0)
         if ((rc = dev_alloc(ctx, ctx->descs, &B.blk, cap))) return rc;
         if ((rc = dev_alloc(ctx, ctx->descs, &B.plist, (size_t)cap))) return rc;
         if ((rc = dev_alloc(ctx, ctx->descs, &B.redo_list, (size_t)cap))) return rc;
+        if ((rc = dev_alloc(ctx, ctx->descs, &B.resume_list, (size_t)cap))) return rc;
         if (ctx->h_blk) (void)hipHostFree(ctx->h_blk);
         ctx->h_blk = nullptr;
         if (hipHostMalloc((void **)&ctx->h_blk, (size_t)cap * sizeof(BzxBlock), 0) != hipSuccess) return BZX_E_NOMEM;
@@ -384,12 +385,22 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         HIP_TRY(ctx, hipMemsetAsync(B.bk_list, 0, items * sizeof(BzxBucket), ctx->stream));
         bzx_launch_bsplit(B, nblk < ncu ? nblk : ncu, ctx->stream);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_b1, ctx->stream));
+        B.bsort_mode = 0;
         bzx_launch_bsort(B, bzx_bsort_blocks_per_cu() * ncu, ctx->stream);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_b2, ctx->stream));
         ctx->bsort_used = true;
+        // blocks in which a bucket gave up (deep repeats): the fill pass writes the order of their finished buckets,
+        // then the general sorter's prefix-doubling rounds finish the leftover groups (both exit at once when the
+        // resume list is empty); blocks the split kernel refused are sorted from scratch
+        BzxBatch Bf = B;
+        Bf.bsort_mode = 1;
+        bzx_launch_bsort(Bf, bzx_bsort_blocks_per_cu() * ncu, ctx->stream);
         BzxBatch Br = B;
         Br.redo = 1;
         Br.ctr_bwt = BZX_CTR_REDO_FETCH;
+        bzx_launch_bwt(Br, grid_for(ctx, nblk, per_cu), ctx->stream);
+        Br.redo = 2;
+        Br.ctr_bwt = BZX_CTR_RESUME_FETCH;
         bzx_launch_bwt(Br, grid_for(ctx, nblk, per_cu), ctx->stream);
         bzx_launch_periodic(B, ctx->n_slots < 64 ? ctx->n_slots : 64, ctx->stream);
     } else if ((stages & STG_BWT) && nblk) {
@@ -520,7 +531,7 @@ static void collect_stage_times(bzx_ctx *ctx)
     ctx->stats.n_buckets = 0;
     ctx->stats.ms_bwt_split = ctx->stats.ms_bwt_sort = ctx->stats.ms_bwt_general = 0.f;
     if (ctx->bsort_used) {
-        ctx->stats.n_redo = ctx->h_counters[BZX_CTR_REDO];
+        ctx->stats.n_redo = ctx->h_counters[BZX_CTR_REDO] + ctx->h_counters[BZX_CTR_RESUME];
         ctx->stats.n_buckets = ctx->h_counters[BZX_CTR_BK_ITEMS];
         (void)hipEventElapsedTime(&ctx->stats.ms_bwt_split, ctx->ev[0], ctx->ev_b1);
         (void)hipEventElapsedTime(&ctx->stats.ms_bwt_sort, ctx->ev_b1, ctx->ev_b2);

@@ -17,9 +17,12 @@
 //                 wave (wave-level LSD passes, digits on which the group agrees are skipped), larger ones by the
 //                 whole workgroup.  L and orig_ptr are written when no ties are left.
 // HBM traffic per block: block read + P written/read + records written once and read once + L written: ~19 n.
-// Blocks that do not finish this way (a bucket still tied after BS_ROUNDS rounds: repeats of hundreds of symbols,
-// periodic blocks; or more split levels than BS_MAX_BIG tracks) are handed, whole, to the general sorter
-// (bzx_bwt.hip, prefix doubling) through B.redo_list; it also detects periodic blocks.
+// A bucket that is still tied after BS_ROUNDS rounds (repeats of hundreds of symbols; identical rotations of a
+// periodic block) keeps what it has: it writes its order so far and its group starts, and the block goes on
+// B.resume_list; a second, short launch of the sort kernel (the fill pass) writes the order of that block's finished
+// buckets, and the general sorter (bzx_bwt.hip) runs its prefix-doubling rounds on the leftover groups only -- it also
+// detects periodic blocks.  Blocks the split kernel cannot handle (more split levels than BS_MAX_BIG
+// tracks) are sorted from scratch by the general sorter (B.redo_list).
 #include <hip/hip_runtime.h>
 #include "bzx_device.h"
 #include "bzx_wg.h"
@@ -39,11 +42,13 @@
 #define BS_BIN2 12                      // bits of the deeper levels
 #define BS_NBIN1 (1u << BS_BIN1)
 #define BS_TAB_WORDS (BS_NBIN1 + (BS_NBIN1 >> 5))
-#define BS_MAX_BK BZX_BK_PER_BLOCK      // buckets one split may produce
-#define BS_MAX_BIG 192                  // oversized bins waiting for a deeper split (per block)
+#define BS_MAX_BK 1024                   // buckets one split (one level of one range) may produce
+#define BS_MAX_BIG 256                  // oversized bins waiting for a deeper split at any one time (ring, per block)
 #define SP_U 4                          // split kernel: groups of four rotations in flight per lane
+#define BS_MAX_DEPTH 255                // deepest split: 15 + 20 x 12 key bits ...
+#define BS_MAX_SPLITS 1024              // ... and at most this many deeper splits per block: beyond, the general sorter
 #ifndef BS_ROUNDS
-#define BS_ROUNDS 32                    // refinement rounds of 50 bits before a bucket gives up (1600 bits)
+#define BS_ROUNDS 8                     // refinement rounds of 50 bits before a bucket gives up (47 + 400 bits)
 #endif
 #define BS_TINY 64                      // groups up to this size are ranked by counting
 #define BS_MED 512                      // ... up to this size by one wave
@@ -98,7 +103,7 @@ __shared__ uint8_t b_b0[BS_MAX_BK];          // bits of the bin index that all b
 __shared__ uint32_t b_inuse[256];
 __shared__ uint8_t b_seq[256];
 __shared__ uint32_t b_scratch[2 * BS_NW];
-__shared__ uint32_t b_bcast[8];              // [0] block, [1] big buckets, [2] item base, [3] big-list length
+__shared__ uint32_t b_bcast[8];              // [0] block, [2] item base, [3] oversized bins pushed so far, [4] ring overflow
 __shared__ uint32_t b_big[BS_MAX_BIG][3];    // oversized bins: {start | buffer << 31, cnt, depth bits}
 
 #define TAB(b) b_tab[(b) + ((b) >> 5)]
@@ -173,7 +178,7 @@ __device__ __forceinline__ void bucket_setup(uint32_t nbk)
 // Returns false when the big list is full.
 template <int BINW>
 __device__ __forceinline__ bool bucket_emit(const BzxBatch &B, uint32_t blk, uint32_t nbk, uint32_t base, uint32_t buf,
-                                            uint32_t depth, uint32_t bits)
+                                            uint32_t depth, uint32_t bits, uint32_t done)
 {
     const uint32_t tid = threadIdx.x;
     if (tid == 0) b_bcast[2] = atomicAdd(&B.counters[BZX_CTR_BK_ITEMS], nbk);
@@ -187,18 +192,20 @@ __device__ __forceinline__ bool bucket_emit(const BzxBatch &B, uint32_t blk, uin
         it.cnt = b_start[k + 1] - b_start[k];
         it.dbits = (depth + b_b0[k]) | (bits << 16);
         if (it.cnt > BS_C) {
-            const uint32_t q = atomicAdd(&b_bcast[3], 1u);
-            if (q < BS_MAX_BIG) {
-                b_big[q][0] = it.start;
-                b_big[q][1] = it.cnt;
-                b_big[q][2] = depth + BINW;
+            const uint32_t q = atomicAdd(&b_bcast[3], 1u);      // ring: entries [done, q] are pending
+            if (q - done < BS_MAX_BIG) {
+                b_big[q % BS_MAX_BIG][0] = it.start;
+                b_big[q % BS_MAX_BIG][1] = it.cnt;
+                b_big[q % BS_MAX_BIG][2] = depth + BINW;
+            } else {
+                b_bcast[4] = 1;                                   // ring full
             }
             it.cnt = 0;                          // the sort kernel skips empty items
         }
         B.bk_list[ibase + k] = it;
     }
     __syncthreads();
-    return b_bcast[3] <= BS_MAX_BIG;
+    return b_bcast[4] == 0;
 }
 
 __device__ __forceinline__ void block_redo(const BzxBatch &B, uint32_t b)
@@ -231,6 +238,8 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
         if (tid == 0) {
             b_bcast[1] = 0;
             b_bcast[3] = 0;
+            b_bcast[4] = 0;
+            B.blk[b].n_mtf = 0xFFFFFFFFu;        // (until the MTF stage: smallest depth, in symbols, at which a bucket gave up)
         }
         __syncthreads();
         {
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
         }
         __syncthreads();
         DIAG_STAMP(101);
-        bool ok = bucket_emit<BS_BIN1>(B, b, nbk, 0, 0, 0, bits);
+        bool ok = bucket_emit<BS_BIN1>(B, b, nbk, 0, 0, 0, bits, 0);
         DIAG_STAMP(102);
 
         // ---- deeper levels: every oversized bin is split by its next BS_BIN2 bits into the other record buffer
@@ -349,12 +358,16 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
             const uint32_t nbig = b_bcast[3];
             __syncthreads();
             if (done >= nbig) break;
-            const uint32_t st = b_big[done][0], cnt = b_big[done][1], depth = b_big[done][2];
+            const uint32_t st = b_big[done % BS_MAX_BIG][0], cnt = b_big[done % BS_MAX_BIG][1], depth = b_big[done % BS_MAX_BIG][2];
             done++;
+            __syncthreads();                                      // (the slot may be reused by this split's pushes)
             const uint32_t base = st & 0x7fffffffu, buf = st >> 31;
             const uint64_t *__restrict__ src = (buf ? rec_b : rec_a) + base;
             uint64_t *__restrict__ dst = (buf ? rec_a : rec_b) + base;
-            if (depth + BS_BIN2 + 32 >= n * bits) {                   // a whole turn of the block is shared: general sorter
+            // a whole turn of the block is shared, or bins are still oversized after BS_MAX_DEPTH key bits / BS_MAX_SPLITS
+            // splits (thousands of rotations sharing long prefixes: near-identical copies of content; every split costs
+            // tens of microseconds on this one workgroup): general sorter, from scratch
+            if (depth + BS_BIN2 + 32 >= n * bits || depth + BS_BIN2 > BS_MAX_DEPTH || done > BS_MAX_SPLITS) {
                 ok = false;
                 break;
             }
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
                 dst[b_start[k] + slot] = ((uint64_t)key << 32) | (r & 0xFFFFFFFFull);
             }
             __syncthreads();
-            ok = bucket_emit<BS_BIN2>(B, b, nbk, base, buf ^ 1u, depth, bits);
+            ok = bucket_emit<BS_BIN2>(B, b, nbk, base, buf ^ 1u, depth, bits, done);
             DIAG_COUNT(104, 1);
             DIAG_COUNT(105, cnt);
         }
@@ -453,6 +466,7 @@ __device__ __forceinline__ BzxBucket uni(BzxBucket b)
     r.blk = uni(b.blk);
     r.start = uni(b.start);
     r.cnt = uni(b.cnt);
+    if (r.cnt >> 31) r.cnt = 0;             // a bucket that gave up in the first launch: nothing for the fill pass
     r.dbits = uni(b.dbits);
     return r;
 }
@@ -689,6 +703,7 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(Bzx
 {
     const uint32_t tid0 = threadIdx.x;
     const uint32_t n_items = B.counters[BZX_CTR_BK_ITEMS] < B.bk_cap ? B.counters[BZX_CTR_BK_ITEMS] : B.bk_cap;
+    if (B.bsort_mode == 1 && B.counters[BZX_CTR_RESUME] == 0) return;          // fill pass: no block needs it
     DIAG_T0();
     // Work items are dealt round-robin (workgroup g sorts items g, g+G, ..: ~250 buckets each, so the load evens out
     // without an atomic fetch on the critical path), which makes the NEXT item known early: its descriptor is loaded
@@ -716,7 +731,9 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(Bzx
         const uint32_t start = it.start & 0x7fffffffu, bits = it.dbits >> 16, depth0 = it.dbits & 0xFFFFu;
         const uint8_t *__restrict__ P = B.pk + BZX_SLAB(B, b) * BZX_PK_STRIDE;
         const uint32_t nbits = n_cur * bits;
-        const bool skip = cnt == 0 || (st_cur & BZX_ST_REDO);      // empty, or the block goes to the general sorter anyway
+        // skipped: empty items; blocks that are sorted from scratch anyway; in the fill pass everything but the finished
+        // buckets of blocks in which some other bucket gave up
+        const bool skip = cnt == 0 || (cnt >> 31) || (st_cur & BZX_ST_REDO) || (B.bsort_mode == 1 && !(st_cur & BZX_ST_RESUME));
         DIAG_STAMP(64);
         if (!skip) {
 #pragma unroll
@@ -910,9 +927,25 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(Bzx
             dcur += 50;
         }
         tid = tid_here();
-        if (fail) {
-            if (tid == 0) block_redo(B, b);
-        } else {
+        if (fail || B.bsort_mode == 1) {
+            // A bucket that gave up keeps what it has: the order so far and the group starts go to the (dead) record
+            // range of the bucket as [group start:1 @32 | rotation:20], the block is queued for the general sorter's
+            // prefix-doubling rounds, which then run on the leftover groups only.  The fill pass writes the same for
+            // the buckets of such a block that did finish (every rank its own group).
+            uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) {
+                const uint32_t p = j * SK_NT + tid;
+                if (p < cnt) sax[p] = (uint64_t)REC_IDX(s_x[(uint32_t)(s_w[p] & W_POS_MASK)]) | ((uint64_t)fbit(p) << 32);
+            }
+            if (fail && tid == 0) {
+                atomicMin(&B.blk[b].n_mtf, dcur / bits);
+                B.bk_list[idx].cnt = cnt | 0x80000000u;          // (the fill pass leaves this item alone)
+                if ((atomicOr(&B.blk[b].status, BZX_ST_RESUME) & BZX_ST_RESUME) == 0)
+                    B.resume_list[atomicAdd(&B.counters[BZX_CTR_RESUME], 1u)] = b;
+            }
+        }
+        {
             uint8_t *__restrict__ L = B.bwt + BZX_SLAB(B, b) * BZX_BLK_STRIDE + start;
 #pragma unroll
             for (uint32_t j = 0; j < BS_E; j++) {

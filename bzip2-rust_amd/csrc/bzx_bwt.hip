@@ -943,6 +943,60 @@ __device__ __attribute__((noinline)) uint32_t big_split(uint64_t *__restrict__ U
     return d + pass;        // TEXT: every listed group was split by the symbols depth .. depth+pass-1
 }
 
+// Resume mode: the bucket sorter (bzx_bsort.hip) left the block's order so far as SAX[r] = [group start:1 @32 |
+// rotation:20] for every rank r.  Builds what the RANK rounds start from: SA[r], and for the ranks in groups of more
+// than one the compacted records [g:20 @44 | sa:20 @8] with their slots.  Returns the number of such ranks;
+// s_bcast[3] = size of the largest group.
+__device__ __attribute__((noinline)) uint32_t resume_load(const uint64_t *__restrict__ SAX, uint32_t n, uint64_t *__restrict__ Unew,
+                                                          uint32_t *__restrict__ Snew, uint32_t *__restrict__ SA)
+{
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_bcast[3] = 0;
+    __syncthreads();
+    uint32_t my_maxgrp = 0, carry_ks = 0, carry_cnt = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += SORT_NT * SORT_E) {
+        const uint32_t k0 = t0 + tid * SORT_E;
+        uint64_t r[SORT_E + 1];
+#pragma unroll
+        for (int j = 0; j <= SORT_E; j++) r[j] = k0 + j < n ? SAX[k0 + j] : (1ull << 32);
+        uint32_t my_ks = 0, my_cnt = 0;
+#pragma unroll
+        for (int j = 0; j < SORT_E; j++) {
+            const uint32_t k = k0 + j;
+            if (k < n) {
+                const bool f0 = k == 0 || ((r[j] >> 32) & 1u), f1 = (r[j + 1] >> 32) & 1u;
+                if (f0) my_ks = k + 1;
+                if (!(f0 && f1)) my_cnt++;
+            }
+        }
+        uint32_t cnt_excl, cnt_total, ks_excl, ks_total;
+        bzx_block_scan_sum_max_lds<SORT_NT>(my_cnt, my_ks, s_scratch, cnt_excl, cnt_total, ks_excl, ks_total);
+        uint32_t ks = ks_excl ? ks_excl : carry_ks;
+        uint32_t o = carry_cnt + cnt_excl;
+#pragma unroll
+        for (int j = 0; j < SORT_E; j++) {
+            const uint32_t k = k0 + j;
+            if (k < n) {
+                const bool f0 = k == 0 || ((r[j] >> 32) & 1u), f1 = (r[j + 1] >> 32) & 1u;
+                if (f0) ks = k + 1;
+                const uint32_t kstart = ks - 1, sa = (uint32_t)r[j] & 0xFFFFFu;
+                if (k - kstart + 1 > my_maxgrp) my_maxgrp = k - kstart + 1;
+                SA[k] = sa;
+                if (!(f0 && f1)) {
+                    Unew[o] = ((uint64_t)kstart << G_SHIFT) | ((uint64_t)sa << TXT_SA_SHIFT);
+                    Snew[o] = k;
+                    o++;
+                }
+            }
+        }
+        if (ks_total) carry_ks = ks_total;
+        carry_cnt += cnt_total;
+    }
+    atomicMax(&s_bcast[3], my_maxgrp);
+    __syncthreads();
+    return carry_cnt;
+}
+
 // diagnostic phase timers (B.dbg != null only in profiling runs): accumulate wall-clock ticks per phase
 #ifdef BZX_DIAG
 #define PHASE_STAMP(slot)                                                     \
@@ -974,8 +1028,8 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         __syncthreads();
         const uint32_t j_ = s_bcast[0];
         __syncthreads();
-        if (j_ >= (B.redo ? B.counters[BZX_CTR_REDO] : B.nblk)) break;
-        const uint32_t b = B.redo ? B.redo_list[j_] : B.blk_first + j_ * B.blk_step;
+        if (j_ >= (B.redo == 2 ? B.counters[BZX_CTR_RESUME] : B.redo ? B.counters[BZX_CTR_REDO] : B.nblk)) break;
+        const uint32_t b = B.redo == 2 ? B.resume_list[j_] : B.redo ? B.redo_list[j_] : B.blk_first + j_ * B.blk_step;
 
         const uint32_t n = B.blk[b].n;
         const uint8_t *__restrict__ T = BZX_BLOCK_PTR(B, B.blk[b]);
@@ -983,6 +1037,17 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         unsigned long long t_blk0 = 0;
         if (DBG_ON && tid == 0) t_last = t_blk0 = wall_clock64();
 
+        uint64_t *ua = ws.u0, *ub = ws.u1;      // ua: current compacted records, ub: the other buffer
+        uint32_t *sa_cur = ws.s0, *sa_alt = ws.s1;
+        uint32_t *orig_out = &B.blk[b].orig_ptr;
+        uint32_t m = 0, depth = 0, frozen_depth = 0xffffffffu;
+        if (B.redo == 2) {
+            // resume: the bucket sorter resolved most rotations; the RANK rounds below finish the leftover groups, all of
+            // which agree on at least blk.n_mtf symbols (the smallest depth at which a bucket gave up)
+            m = resume_load(B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N, n, ua, sa_cur, ws.sa);
+            depth = B.blk[b].n_mtf;
+            frozen_depth = depth;              // (also marks the group sizes as not measured by a rerank)
+        } else {
         // ---- A: bytes in use -> dense symbol ids; symbols per key
         if (tid < 256) s_inuse[tid] = 0;
         __syncthreads();
@@ -1058,15 +1123,13 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         if (DBG_STOP(2)) continue;
 
         // ---- R: ranks by the first four bytes
-        uint64_t *ua = ws.u0, *ub = ws.u1;      // ua: current compacted records, ub: the other buffer
-        uint32_t *sa_cur = ws.s0, *sa_alt = ws.s1;
-        uint32_t *orig_out = &B.blk[b].orig_ptr;
-        uint32_t m = rerank<MODE_INIT>(ws.u1, nullptr, n, ua, sa_cur, ws.isa, ws.sa, L, orig_out, T, n);
+        m = rerank<MODE_INIT>(ws.u1, nullptr, n, ua, sa_cur, ws.isa, ws.sa, L, orig_out, T, n);
         PHASE_STAMP(2);
         if (DBG_STOP(3)) continue;
 
         // ---- TEXT rounds: csym more symbols per round; oversized groups are split by single symbols first
-        uint32_t depth = ksym, round = 0, frozen_depth = 0xffffffffu;
+        depth = ksym;
+        uint32_t round = 0;
         while (m > 0 && depth < n && round < TEXT_ROUNDS) {
             const uint32_t maxgrp = s_bcast[3];
             __syncthreads();
@@ -1092,6 +1155,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
             if ((uint64_t)m * 10 > (uint64_t)m_before * 9) break;      // (almost) nothing but deep repeats / frozen groups left
         }
         __syncthreads();
+        }
         if (DBG_STOP_ANY) continue;
 
         // ---- RANK rounds (deep repeats): build ISA once, then prefix doubling on ranks

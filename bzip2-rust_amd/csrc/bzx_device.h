@@ -19,10 +19,11 @@
 
 #define BZX_IN_RAW (1ull << 63)
 #define BZX_ST_PERIODIC 1u         // block is u^k, k>1: identical rotations exist
-#define BZX_ST_REDO 2u             // the bucket sorter handed the block to the general sorter (deep repeats)
+#define BZX_ST_REDO 2u             // the split kernel handed the block to the general sorter, to be sorted from scratch
+#define BZX_ST_RESUME 4u           // a bucket gave up (deep repeats): the general sorter finishes the leftover groups
 #define BZX_PK_STRIDE 900352u      // per-block stride of the packed blocks (bzx_pack.h): (n + 207 symbols) * 8 bits max
 #ifndef BZX_BK_PER_BLOCK
-#define BZX_BK_PER_BLOCK 1024u     // bucket work items reserved per block
+#define BZX_BK_PER_BLOCK 2048u     // bucket work items reserved per block (average over the blocks of a batch)
 #endif
 
 // counters[] slots (BzxBatch.counters, zeroed per batch)
@@ -32,6 +33,8 @@
 #define BZX_CTR_REDO 10            // blocks handed to the general sorter
 #define BZX_CTR_SPLIT_FETCH 11     // blocks fetched by the split kernel
 #define BZX_CTR_REDO_FETCH 12      // blocks fetched by the general sorter in redo mode
+#define BZX_CTR_RESUME 13          // blocks whose leftover groups the general sorter finishes (resume_list)
+#define BZX_CTR_RESUME_FETCH 14
 #define BZX_CTR_STAT0 16           // [16..31] diagnostics of the bucket sorter (rounds, leftovers, ...)
 
 // One bucket of rotations: ranks [start, start+cnt) of block blk, all sharing the first `dbits` bits; records
@@ -104,7 +107,9 @@ struct BzxBatch {
     BzxBucket *bk_list;     // [bk_cap] bucket work items (zeroed per batch)
     uint32_t bk_cap;
     uint32_t *redo_list;    // [nblk] blocks for the general sorter
-    uint32_t redo;          // general sorter: take the blocks from redo_list (count = counters[BZX_CTR_REDO])
+    uint32_t *resume_list;  // [nblk] blocks the general sorter finishes (BZX_ST_RESUME)
+    uint32_t redo;          // general sorter: 1 = sort the blocks of redo_list from scratch; 2 = finish the blocks of resume_list
+    uint32_t bsort_mode;    // bucket sort kernel: 0 = sort; 1 = fill pass (write the order of the finished buckets of BZX_ST_RESUME blocks)
     uint32_t n_slots;
     uint32_t dbg_stop;       // diagnostics only: leave the BWT kernel after phase k (0 = run everything)
     unsigned long long *dbg; // optional [64] phase timers (100 MHz ticks), null in production

@@ -336,7 +336,8 @@ __device__ static void main_qsort3(uint32_t *ptr, const uint8_t *block, const ui
 #define CLEARMASK (~SETMASK)
 #define BIGFREQ(b) (ftab[((b) + 1) << 8] - ftab[(b) << 8])
 
-/* block must have N_OVERSHOOT writable bytes after nblock; quadrant nblock+N_OVERSHOOT entries; ftab 65537. */
+/* block must have N_OVERSHOOT writable bytes after nblock; quadrant nblock+N_OVERSHOOT entries; ftab 65537.
+   Everything after libbz2's set-up loops: bucket order, bucket sorts under the work budget, copying, quadrants. */
 __device__ static void main_sort(uint32_t *ptr, uint8_t *block, uint16_t *quadrant, uint32_t *ftab, int32_t nblock,
                       int32_t *budget, PeriodInfo *pi)
 {
@@ -346,28 +347,7 @@ __device__ static void main_sort(uint32_t *ptr, uint8_t *block, uint16_t *quadra
     uint8_t c1;
     uint16_t s;
 
-    for (i = 65536; i >= 0; i--) ftab[i] = 0;
-
-    j = block[0] << 8;
-    for (i = nblock - 1; i >= 0; i--) {
-        quadrant[i] = 0;
-        j = (j >> 8) | (((uint16_t)block[i]) << 8);
-        ftab[j]++;
-    }
-    for (i = 0; i < N_OVERSHOOT; i++) {
-        block[nblock + i] = block[i];
-        quadrant[nblock + i] = 0;
-    }
-    for (i = 1; i <= 65536; i++) ftab[i] += ftab[i - 1];
-
-    s = (uint16_t)(block[0] << 8);
-    for (i = nblock - 1; i >= 0; i--) {
-        s = (uint16_t)((s >> 8) | (block[i] << 8));
-        j = (int32_t)ftab[s] - 1;
-        ftab[s] = (uint32_t)j;
-        ptr[j] = (uint32_t)i;
-    }
-
+    // (ftab, ptr, quadrant and the overshoot bytes were set up by main_setup_coop, all lanes)
     for (i = 0; i <= 255; i++) {
         big_done[i] = 0;
         running_order[i] = i;
@@ -446,13 +426,102 @@ __device__ static void main_sort(uint32_t *ptr, uint8_t *block, uint16_t *quadra
 }
 
 
+
+// ---- cooperative set-up of the main sort --------------------------------------------------------------------------
+// libbz2's mainSort starts with three loops over the block on one thread: a 65,536-bin histogram of the 2-byte
+// prefixes key(i) = block[i] << 8 | block[i+1], its prefix sums, and the pointer fill "for i = n-1 .. 0:
+// ptr[--ftab[key(i)]] = i", which leaves every 2-byte bucket holding its rotations in ASCENDING order and ftab[s]
+// at the bucket's start.  The same result, by all lanes: histogram with atomics, an exclusive prefix over the bins,
+// and a stable counting sort of i by key(i) as two stable 8-bit passes (low byte, then high byte), each with
+// per-lane counts over contiguous chunks.  On one lane these loops were ~1.8 M dependent global read-modify-writes,
+// most of the two seconds a periodic block used to take.
+#define PER_NT 256
+__device__ static void main_setup_coop(uint32_t *ptr, uint32_t *tmp, uint8_t *block, uint16_t *quadrant, uint32_t *ftab,
+                                       uint32_t *cnt /* [PER_NT][256] */, int32_t nblock)
+{
+    __shared__ uint32_t s_tot[256];
+    __shared__ uint32_t s_base[256];
+    const uint32_t tid = threadIdx.x;
+    const int32_t chunk = (nblock + PER_NT - 1) / PER_NT;
+    const int32_t ca = (int32_t)tid * chunk < nblock ? (int32_t)tid * chunk : nblock;
+    const int32_t cb = ca + chunk < nblock ? ca + chunk : nblock;
+    for (int32_t i = (int32_t)tid; i <= 65536; i += PER_NT) ftab[i] = 0;
+    for (int32_t i = (int32_t)tid; i < nblock + N_OVERSHOOT; i += PER_NT) quadrant[i] = 0;
+    if (tid < N_OVERSHOOT) block[nblock + tid] = block[tid];
+    __syncthreads();
+    // histogram (consecutive equal keys of a lane are added at once: periodic blocks have few distinct keys)
+    {
+        uint32_t run_key = 0, run = 0;
+        for (int32_t i = ca; i < cb; i++) {
+            const uint32_t key = ((uint32_t)block[i] << 8) | block[i + 1];      // block[nblock] = block[0]
+            if (run && key != run_key) {
+                atomicAdd(&ftab[run_key], run);
+                run = 0;
+            }
+            run_key = key;
+            run++;
+        }
+        if (run) atomicAdd(&ftab[run_key], run);
+    }
+    __syncthreads();
+    // exclusive prefix over the 65,536 bins: lane t owns bins [256 t, 256 t + 256)
+    {
+        uint32_t sum = 0;
+        for (uint32_t k = 0; k < 256; k++) sum += ftab[tid * 256 + k];
+        s_tot[tid] = sum;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (uint32_t t = 0; t < tid; t++) pre += s_tot[t];
+        for (uint32_t k = 0; k < 256; k++) {
+            const uint32_t c = ftab[tid * 256 + k];
+            ftab[tid * 256 + k] = pre;
+            pre += c;
+        }
+        if (tid == 0) ftab[65536] = (uint32_t)nblock;
+    }
+    __syncthreads();
+    // stable counting sort of i by key(i): pass 0 by block[i+1] (identity -> tmp), pass 1 by block[i] (tmp -> ptr)
+    for (int pass = 0; pass < 2; pass++) {
+        for (int32_t c = 0; c < 256; c++) cnt[tid * 256 + c] = 0;
+        for (int32_t x = ca; x < cb; x++) {
+            const uint32_t i = pass ? tmp[x] : (uint32_t)x;
+            cnt[tid * 256 + block[i + (pass ? 0 : 1)]]++;
+        }
+        __syncthreads();
+        {
+            uint32_t run = 0;                       // column tid: lanes in order
+            for (uint32_t t = 0; t < PER_NT; t++) {
+                const uint32_t v = cnt[t * 256 + tid];
+                cnt[t * 256 + tid] = run;
+                run += v;
+            }
+            s_tot[tid] = run;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t acc = 0;
+            for (int32_t c = 0; c < 256; c++) {
+                s_base[c] = acc;
+                acc += s_tot[c];
+            }
+        }
+        __syncthreads();
+        uint32_t *dst = pass ? ptr : tmp;
+        for (int32_t x = ca; x < cb; x++) {
+            const uint32_t i = pass ? tmp[x] : (uint32_t)x;
+            const uint32_t c = block[i + (pass ? 0 : 1)];
+            dst[s_base[c] + cnt[tid * 256 + c]++] = i;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- cooperative form of the fallback sort ---------------------------------------------------------------
 // Same algorithm and, step for step, the same permutation as fallback_sort above (libbz2 fallbackSort), run by a
 // whole workgroup: the position-parallel parts (bucket fill, equivalence-class assignment, header bits) are
 // spread over the lanes, lane 0 walks the buckets and runs the 3-way quicksort, and large buckets whose keys
 // are all equal -- the common case in a periodic block once the doubling depth passes the period; libbz2's
 // quicksort provably leaves such a bucket untouched -- are recognised in parallel and skipped.
-#define PER_NT 256
 #define PER_COOP_MIN 4096
 
 __device__ static void fallback_sort_coop(const uint8_t *__restrict__ T, uint32_t *fmap, uint32_t *eclass,
@@ -621,6 +690,7 @@ __global__ __launch_bounds__(PER_NT) void bzx_periodic_kernel(BzxBatch B)
         if (n >= 10000) {
             for (int32_t i = (int32_t)threadIdx.x; i < n; i += PER_NT) block[i] = T[i];
             __syncthreads();
+            main_setup_coop(ptr, eclass, block, quadrant, ftab, cnt, n);
             if (threadIdx.x == 0) {
                 int32_t budget = n * ((30 - 1) / 3);
                 PeriodInfo pinfo;

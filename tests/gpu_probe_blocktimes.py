@@ -27,7 +27,7 @@ out = lib.compress_buffer(data, 9)
 st = lib.stats(); nb = st.nblk
 us = (C.c_uint32 * nb)(); ns = (C.c_uint32 * nb)(); iu = (C.c_uint32 * nb)()
 lib._check(L.bzx_dbg_block_times(lib.ctx, nb, us, ns, iu))
-t = (C.c_ulonglong * 64)(); lib._check(L.bzx_dbg_phase_timers(lib.ctx, 0, t))
+t = (C.c_ulonglong * 128)(); lib._check(L.bzx_dbg_phase_timers(lib.ctx, 0, t))
 us = np.array(list(us)); order = np.argsort(-us)
 print(kind, "blocks", nb, "bwt ms", st.ms_bwt, "per-block us: median", int(np.median(us)), "p90", int(np.percentile(us, 90)), "max", int(us.max()))
 print("slowest:", [(int(b), int(us[b]), int(ns[b]), int(iu[b])) for b in order[:8]])

@@ -43,6 +43,11 @@ def run(name, data, ref="oracle"):
         print("   split kernel: " + "  ".join(f"{SPLIT_SLOTS[i]} {100.0*t[i]/tot:.1f}%" for i in SPLIT_SLOTS),
               f" [sum {tot/100.0/max(1,st.nblk):.0f} us per block]")
         print("   counts: " + "  ".join(f"{v}={t[k]}" for k, v in COUNTS.items()))
+        gen = {0: "A+hist", 1: "lsd4", 2: "rerank0", 3: "tail", 4: "rank-rerank", 5: "isa-build", 6: "rank-segsort", 7: "rank-bigsplit"}
+        tg = sum(t[i] for i in range(32)) or 1
+        print("   general sorter: " + "  ".join(f"{v} {t[k]/100.0/max(1,st.n_redo):.0f}us" for k, v in gen.items()),
+              f" text-rounds {sum(t[i] for i in range(8, 32))/100.0/max(1,st.n_redo):.0f}us  [per block handed over]",
+              " rank rounds m/maxgrp:", [(t[52 + 2 * r], t[53 + 2 * r]) for r in range(6)])
     t = time.time()
     want = o.compress_mt(data, 9) if ref == "oracle" else bz2.compress(data, 9)
     dr = time.time() - t

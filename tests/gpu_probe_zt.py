@@ -1,0 +1,15 @@
+import sys, time
+sys.path.insert(0, "tests")
+from bzx_ctypes import *
+o = Oracle(); lib = BzxLib(max_blocks=16)
+tail = b"\0\0\0\0\xfb" * 166350 + b"\0\0\0\0\x04"
+for name, img in (("tail831k", tail), ("tail-small", b"\0\0\0\0\xfb" * 3000 + b"\0\0\0\0\x04")):
+    print("start", name, len(img), flush=True)
+    t = time.time(); L, orig, st = lib.stage_bwt(img); dt = time.time() - t
+    Lo, oo = o.bwt(img)
+    print(f"  {dt*1e3:.1f} ms  {'OK' if (L, orig) == (Lo, oo) else 'MISMATCH'} status {st}", flush=True)
+data = b"\0" * (64 << 20)
+print("start 64MiB zeros", flush=True)
+t = time.time(); z = lib.compress_buffer(data, 9); dt = time.time() - t
+import bz2
+print(f"  {dt*1e3:.1f} ms {'OK' if z == bz2.compress(data, 9) else 'MISMATCH'}", lib.stats().nblk, lib.stats().n_periodic, flush=True)
