@@ -21,6 +21,7 @@
 void bzx_launch_bwt(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_bsplit(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_bsort(const BzxBatch &B, uint32_t grid, hipStream_t stream);
+void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_periodic(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_mtf(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_huffman(const BzxBatch &B, uint32_t grid, hipStream_t stream);
@@ -79,6 +80,7 @@ struct bzx_ctx {
     // second stream: MTF of finished blocks runs beside the last (partial) round of the sort
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bend = nullptr;
+    hipEvent_t ev_b3 = nullptr, ev_b4 = nullptr;     // ... around the rank rounds
     hipEvent_t ev_b1 = nullptr, ev_b2 = nullptr;     // bucket sorter: after the split kernel, after the sort kernel
     bool bsort_used = false;
     uint32_t *h_counters = nullptr;                   // pinned copy of d_counters after a run
@@ -207,6 +209,7 @@ static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk, uint32_t nslab = 0)
         if ((rc = dev_alloc(ctx, ctx->slabs, &B.rec_b, (size_t)cap * BZX_MAX_N))) return rc;
         if ((rc = dev_alloc(ctx, ctx->slabs, &B.bk_list, (size_t)cap * BZX_BK_PER_BLOCK))) return rc;
         B.bk_cap = cap * BZX_BK_PER_BLOCK;
+        if ((rc = dev_alloc(ctx, ctx->slabs, &B.rk_list, (size_t)B.bk_cap))) return rc;
     }
     if ((rc = dev_alloc(ctx, ctx->slabs, &ctx->d_outbuf, (size_t)cap * (BZX_OUT_STRIDE / 4)))) return rc;
     ctx->cap_slabs = cap;
@@ -276,11 +279,12 @@ extern "C" int bzx_ctx_create(int device, uint32_t max_blocks, bzx_ctx **out)
     if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreate(&ctx->ev_fork) != hipSuccess || hipEventCreate(&ctx->ev_join) != hipSuccess ||
         hipEventCreate(&ctx->ev_bend) != hipSuccess || hipEventCreate(&ctx->ev_b1) != hipSuccess ||
-        hipEventCreate(&ctx->ev_b2) != hipSuccess) {
+        hipEventCreate(&ctx->ev_b2) != hipSuccess || hipEventCreate(&ctx->ev_b3) != hipSuccess ||
+        hipEventCreate(&ctx->ev_b4) != hipSuccess) {
         bzx_ctx_destroy(ctx);
         return BZX_E_HIP;
     }
-    bool ok = hipMalloc((void **)&ctx->d_counters, 64 * sizeof(uint32_t)) == hipSuccess &&
+    bool ok = hipMalloc((void **)&ctx->d_counters, BZX_N_COUNTERS * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&ctx->d_scalars, 8 * sizeof(uint64_t)) == hipSuccess &&
               hipHostMalloc((void **)&ctx->h_scalars, 8 * sizeof(uint64_t), 0) == hipSuccess &&
               hipHostMalloc((void **)&ctx->h_counters, 64 * sizeof(uint32_t), 0) == hipSuccess;
@@ -315,6 +319,8 @@ extern "C" void bzx_ctx_destroy(bzx_ctx *ctx)
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ev_b1) (void)hipEventDestroy(ctx->ev_b1);
     if (ctx->ev_b2) (void)hipEventDestroy(ctx->ev_b2);
+    if (ctx->ev_b3) (void)hipEventDestroy(ctx->ev_b3);
+    if (ctx->ev_b4) (void)hipEventDestroy(ctx->ev_b4);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -367,7 +373,7 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
     B.nblk = nblk;
     B.counters = ctx->d_counters;
     if (B.blk_step == 0) B.blk_step = 1;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 64 * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, BZX_N_COUNTERS * sizeof(uint32_t), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     B.ctr_bwt = 0;
     B.ctr_mtf = 1;
@@ -385,16 +391,50 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         HIP_TRY(ctx, hipMemsetAsync(B.bk_list, 0, items * sizeof(BzxBucket), ctx->stream));
         bzx_launch_bsplit(B, nblk < ncu ? nblk : ncu, ctx->stream);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_b1, ctx->stream));
+        // Blocks the split kernel refused (oversized bins beyond its depth / split limits: a handful in real data)
+        // are sorted from scratch by the general sorter, one workgroup each, 10-60 ms: started right away on the
+        // high-priority side stream, in sort slots of their own, beside the bucket sort of everything else.
+        const bool early = ctx->n_slots >= 64;
+        const uint32_t n_early = 32;
+        B.rk_slot0 = early ? n_early : 0;
+        B.slot_base = 0;
+        B.redo_once = 0;
+        if (early) {
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_b1, 0));
+            BzxBatch Be = B;
+            Be.redo = 1;
+            Be.ctr_bwt = BZX_CTR_REDO_FETCH;
+            Be.redo_once = 1;
+            bzx_launch_bwt(Be, n_early, ctx->aux);
+        }
         B.bsort_mode = 0;
         bzx_launch_bsort(B, bzx_bsort_blocks_per_cu() * ncu, ctx->stream);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_b2, ctx->stream));
         ctx->bsort_used = true;
-        // blocks in which a bucket gave up (deep repeats): the fill pass writes the order of their finished buckets,
-        // then the general sorter's prefix-doubling rounds finish the leftover groups (both exit at once when the
-        // resume list is empty); blocks the split kernel refused are sorted from scratch
+        // the blocks in which a bucket gave up (deep repeats): the fill pass writes the order of their finished
+        // buckets and enters their ranks into the block's rank array (inside the general sorter's slots from rk_slot0
+        // on), prefix-doubling rounds over the open buckets finish the leftover groups -- any workgroup on any bucket,
+        // each launch exits at once when nothing is open.  Then the general sorter takes what is left: refused blocks
+        // beyond the early launch's 32, and resume blocks still open after the rank rounds (periodic blocks, more
+        // resume blocks than rank arrays).
         BzxBatch Bf = B;
         Bf.bsort_mode = 1;
         bzx_launch_bsort(Bf, bzx_bsort_blocks_per_cu() * ncu, ctx->stream);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_b3, ctx->stream));
+        if (early) {
+            // blocks with an oversized bin (no rank array): their leftover groups go to the general sorter's
+            // prefix-doubling rounds, on the side stream again, while the rank rounds finish all other resume blocks
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_b3, 0));
+            BzxBatch Be = B;
+            Be.redo = 2;
+            Be.ctr_bwt = BZX_CTR_RESUME_FETCH2;
+            Be.redo_once = 2;
+            bzx_launch_bwt(Be, n_early, ctx->aux);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+        }
+        bzx_launch_brank(B, bzx_bsort_blocks_per_cu() * ncu, ctx->stream);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_b4, ctx->stream));
+        if (early) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         BzxBatch Br = B;
         Br.redo = 1;
         Br.ctr_bwt = BZX_CTR_REDO_FETCH;
@@ -529,13 +569,20 @@ static void collect_stage_times(bzx_ctx *ctx)
     ctx->stats.ms_bwt = ms[0];
     ctx->stats.n_redo = 0;
     ctx->stats.n_buckets = 0;
-    ctx->stats.ms_bwt_split = ctx->stats.ms_bwt_sort = ctx->stats.ms_bwt_general = 0.f;
+    ctx->stats.ms_bwt_split = ctx->stats.ms_bwt_sort = ctx->stats.ms_bwt_general = ctx->stats.ms_bwt_rank = 0.f;
+    ctx->stats.n_open_buckets = ctx->stats.n_open_left = ctx->stats.n_resume_left = ctx->stats.n_from_scratch = 0;
     if (ctx->bsort_used) {
         ctx->stats.n_redo = ctx->h_counters[BZX_CTR_REDO] + ctx->h_counters[BZX_CTR_RESUME];
         ctx->stats.n_buckets = ctx->h_counters[BZX_CTR_BK_ITEMS];
         (void)hipEventElapsedTime(&ctx->stats.ms_bwt_split, ctx->ev[0], ctx->ev_b1);
         (void)hipEventElapsedTime(&ctx->stats.ms_bwt_sort, ctx->ev_b1, ctx->ev_b2);
         (void)hipEventElapsedTime(&ctx->stats.ms_bwt_general, ctx->ev_b2, ctx->ev[1]);
+        (void)hipEventElapsedTime(&ctx->stats.ms_bwt_rank, ctx->ev_b3, ctx->ev_b4);
+        ctx->stats.n_open_buckets = ctx->h_counters[BZX_CTR_RK_ITEMS];
+        ctx->stats.n_open_left = ctx->h_counters[BZX_CTR_RK_OPEN];
+        ctx->stats.n_resume_left = ctx->h_counters[BZX_CTR_RESUME_LEFT];
+        ctx->stats.n_from_scratch = ctx->h_counters[BZX_CTR_REDO];
+
     }
     ctx->stats.bwt_launches = ctx->bwt_launches;
     ctx->stats.ms_mtf = ms[1];
@@ -569,7 +616,7 @@ extern "C" int bzx_stage_bwt(bzx_ctx *ctx, const uint8_t *blk, size_t n, uint8_t
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_blk, ctx->B.blk, sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *orig_ptr = ctx->h_blk[0].orig_ptr;
-    if (status) *status = ctx->h_blk[0].status;
+    if (status) *status = ctx->h_blk[0].status & BZX_ST_PERIODIC;
     return BZX_OK;
 }
 

@@ -45,10 +45,14 @@
 #define BS_MAX_BK 1024                   // buckets one split (one level of one range) may produce
 #define BS_MAX_BIG 256                  // oversized bins waiting for a deeper split at any one time (ring, per block)
 #define SP_U 4                          // split kernel: groups of four rotations in flight per lane
+#ifndef BS_MAX_DEPTH
 #define BS_MAX_DEPTH 255                // deepest split: 15 + 20 x 12 key bits ...
+#endif
+#ifndef BS_MAX_SPLITS
 #define BS_MAX_SPLITS 1024              // ... and at most this many deeper splits per block: beyond, the general sorter
+#endif
 #ifndef BS_ROUNDS
-#define BS_ROUNDS 8                     // refinement rounds of 50 bits before a bucket gives up (47 + 400 bits)
+#define BS_ROUNDS 5                     // refinement rounds of 50 bits before a bucket gives up (47 + 400 bits)
 #endif
 #define BS_TINY 64                      // groups up to this size are ranked by counting
 #define BS_MED 512                      // ... up to this size by one wave
@@ -208,6 +212,31 @@ __device__ __forceinline__ bool bucket_emit(const BzxBatch &B, uint32_t blk, uin
     return b_bcast[4] == 0;
 }
 
+// An oversized bin the split gives up on (depth or split limit: thousands of rotations sharing a long prefix) is left
+// as ONE group of tied ranks in the resume format ([group start:1 @32 | rotation:20], see the sort kernel), and the
+// block joins the resume blocks WITHOUT a rank array: every other bucket is sorted as usual, but the leftover groups
+// of the whole block are finished by the general sorter's prefix-doubling rounds -- the bucket-level rank rounds
+// cannot take part, because doubling the depth is only valid when every tied group of the block is refined in every
+// round, and this one is too big for them.  rec_a / rec_b: the block's slabs.
+__device__ __forceinline__ void emit_giant(const BzxBatch &B, uint32_t blk, uint64_t *rec_a, const uint64_t *rec_b,
+                                           uint32_t st, uint32_t cnt, uint32_t depth, uint32_t bits)
+{
+    const uint32_t tid = threadIdx.x, base = st & 0x7fffffffu;
+    const uint64_t *src = ((st >> 31) ? rec_b : rec_a) + base;      // (may be the very range written below)
+    for (uint32_t i = tid; i < cnt; i += BS_NT) {
+        const uint64_t r = src[i];
+        rec_a[base + i] = (uint64_t)REC_IDX(r) | (i == 0 ? 1ull << 32 : 0ull);
+    }
+    if (tid == 0) {
+        atomicMin(&B.blk[blk].n_mtf, depth / bits);
+        if ((atomicOr(&B.blk[blk].status, BZX_ST_RESUME) & BZX_ST_RESUME) == 0) {
+            B.resume_list[atomicAdd(&B.counters[BZX_CTR_RESUME], 1u)] = blk;
+            B.blk[blk].n_selectors = 0xFFFFFFFFu;                  // no rank array
+        }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void block_redo(const BzxBatch &B, uint32_t b)
 {
     if ((atomicOr(&B.blk[b].status, BZX_ST_REDO) & BZX_ST_REDO) == 0)
@@ -240,6 +269,7 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
             b_bcast[3] = 0;
             b_bcast[4] = 0;
             B.blk[b].n_mtf = 0xFFFFFFFFu;        // (until the MTF stage: smallest depth, in symbols, at which a bucket gave up)
+            B.blk[b].n_groups = 0;               // (until the Huffman stage: buckets that gave up and are still open)
         }
         __syncthreads();
         {
@@ -364,12 +394,16 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
             const uint32_t base = st & 0x7fffffffu, buf = st >> 31;
             const uint64_t *__restrict__ src = (buf ? rec_b : rec_a) + base;
             uint64_t *__restrict__ dst = (buf ? rec_a : rec_b) + base;
-            // a whole turn of the block is shared, or bins are still oversized after BS_MAX_DEPTH key bits / BS_MAX_SPLITS
-            // splits (thousands of rotations sharing long prefixes: near-identical copies of content; every split costs
-            // tens of microseconds on this one workgroup): general sorter, from scratch
-            if (depth + BS_BIN2 + 32 >= n * bits || depth + BS_BIN2 > BS_MAX_DEPTH || done > BS_MAX_SPLITS) {
+            // a whole turn of the block is shared (periodic blocks): general sorter, from scratch
+            if (depth + BS_BIN2 + 32 >= n * bits) {
                 ok = false;
                 break;
+            }
+            // still oversized after BS_MAX_DEPTH key bits, or BS_MAX_SPLITS splits spent on this block (near-identical
+            // copies of content; every split costs tens of microseconds on this one workgroup): the bin stays one group
+            if (depth + BS_BIN2 > BS_MAX_DEPTH || done > BS_MAX_SPLITS) {
+                emit_giant(B, b, rec_a, rec_b, st, cnt, depth, bits);
+                continue;
             }
             constexpr uint32_t NB2 = 1u << BS_BIN2;
             for (uint32_t i = tid; i < NB2 + (NB2 >> 5); i += BS_NT) b_tab[i] = 0;
@@ -696,6 +730,17 @@ __device__ __forceinline__ bool any_big(uint32_t base, uint32_t s, uint32_t t, u
     return big;
 }
 
+// Rank array (rank of every rotation, uint32[BZX_MAX_N]) of the k-th block of resume_list: the sort slots of the
+// general sorter hold eight such arrays each and are idle while the rank rounds run.  nullptr: none left.
+__device__ __forceinline__ uint32_t *rank_array(const BzxBatch &B, uint32_t k)
+{
+    if (k == 0xFFFFFFFFu || B.rk_slot0 + (k >> 3) >= B.n_slots) return nullptr;      // (~0: a block with an oversized bin)
+    const BzxSortWs w = B.sort_ws[B.rk_slot0 + (k >> 3)];
+    const uint32_t q = k & 7u;
+    uint32_t *base = q < 2 ? (uint32_t *)w.u0 : q < 4 ? (uint32_t *)w.u1 : q == 4 ? w.s0 : q == 5 ? w.s1 : q == 6 ? w.isa : w.sa;
+    return base + (q < 4 && (q & 1u) ? BZX_MAX_N : 0u);
+}
+
 #ifndef SK_WAVES_PER_SIMD
 #define SK_WAVES_PER_SIMD 4             // 128 VGPRs: no spills (at 80 the round loop spills ~40 registers to scratch)
 #endif
@@ -933,16 +978,29 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(Bzx
             // prefix-doubling rounds, which then run on the leftover groups only.  The fill pass writes the same for
             // the buckets of such a block that did finish (every rank its own group).
             uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
+            // (fill pass: the finished buckets also enter their -- final -- ranks into the block's rank array)
+            uint32_t *__restrict__ isa = fail ? nullptr : rank_array(B, uni(B.blk[b].n_selectors));
 #pragma unroll
             for (uint32_t j = 0; j < BS_E; j++) {
                 const uint32_t p = j * SK_NT + tid;
-                if (p < cnt) sax[p] = (uint64_t)REC_IDX(s_x[(uint32_t)(s_w[p] & W_POS_MASK)]) | ((uint64_t)fbit(p) << 32);
+                if (p < cnt) {
+                    const uint32_t rot = REC_IDX(s_x[(uint32_t)(s_w[p] & W_POS_MASK)]);
+                    // (bit 33: the rank's entry in the rank array is due -- all of them for a bucket that just gave up)
+                    sax[p] = (uint64_t)rot | ((uint64_t)fbit(p) << 32) | (fail ? 1ull << 33 : 0ull);
+                    if (isa) isa[rot] = start + p;
+                }
             }
             if (fail && tid == 0) {
                 atomicMin(&B.blk[b].n_mtf, dcur / bits);
                 B.bk_list[idx].cnt = cnt | 0x80000000u;          // (the fill pass leaves this item alone)
-                if ((atomicOr(&B.blk[b].status, BZX_ST_RESUME) & BZX_ST_RESUME) == 0)
-                    B.resume_list[atomicAdd(&B.counters[BZX_CTR_RESUME], 1u)] = b;
+                B.rk_list[atomicAdd(&B.counters[BZX_CTR_RK_ITEMS], 1u)] = idx;
+                atomicAdd(&B.counters[BZX_CTR_RK_OPEN], 1u);
+                atomicAdd(&B.blk[b].n_groups, 1u);
+                if ((atomicOr(&B.blk[b].status, BZX_ST_RESUME) & BZX_ST_RESUME) == 0) {
+                    const uint32_t k = atomicAdd(&B.counters[BZX_CTR_RESUME], 1u);
+                    B.resume_list[k] = b;
+                    B.blk[b].n_selectors = k;
+                }
             }
         }
         {
@@ -966,6 +1024,296 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(Bzx
         st_cur = uni(st_nx);
     }
     DIAG_FLUSH();
+}
+
+
+// ---- rank rounds: the buckets that gave up, finished by prefix doubling ---------------------------------------
+// A bucket gives up when some of its rotations still agree after BS_ROUNDS refinement rounds (deep repeats).  Its
+// ranks and group starts were written back as [group start:1 @32 | rotation:20]; the fill pass did the same for the
+// finished buckets of the block and entered their ranks into the block's rank array.  From there on the leftover
+// groups -- all inside one bucket, so at most BS_C ranks -- are refined by the ranks of the rotations h symbols
+// ahead (h = the block's smallest give-up depth, doubling every round): exactly the refinement round of the sort
+// kernel with ISA[(rotation + h) mod n] in place of the next 50 key bits.  A round is two launches: every open
+// bucket sorts its groups by the current ranks (sort kernel), then every open bucket enters the new group heads into
+// the rank array (update kernel) -- nobody reads the array while it changes.  Any workgroup takes any bucket.
+
+// Next RK_CHUNK work items of a launch, for the whole workgroup: returns the first index and, in `open`, one bit
+// per item that is still open (after a few rounds most buckets are finished; their flags are tested 16 at a time
+// instead of one fetch each).  Dynamic rather than dealt round-robin: compute units may be busy with the general
+// sorter's early launch, and a workgroup that becomes resident late must not find a fixed share waiting for it.
+#define RK_CHUNK 16
+__device__ __forceinline__ uint32_t rk_fetch_chunk(const BzxBatch &B, uint32_t n_items, uint32_t &open)
+{
+    __shared__ uint32_t s_fetch[2];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint32_t base = 0;
+        if (threadIdx.x == 0) base = atomicAdd(&B.counters[B.rk_fetch], (uint32_t)RK_CHUNK);
+        base = __shfl(base, 0);
+        const uint32_t i = base + threadIdx.x;
+        const bool op = threadIdx.x < RK_CHUNK && i < n_items && !(B.bk_list[B.rk_list[i]].dbits >> 31);
+        const uint64_t m = __ballot(op);
+        if (threadIdx.x == 0) {
+            s_fetch[0] = base;
+            s_fetch[1] = (uint32_t)m;
+        }
+    }
+    __syncthreads();
+    open = s_fetch[1];
+    return s_fetch[0];
+}
+
+__global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_sort_kernel(BzxBatch B)
+{
+    if (B.counters[BZX_CTR_RK_OPEN] == 0) return;
+    const uint32_t n_items = B.counters[BZX_CTR_RK_ITEMS];
+    uint32_t chunk0 = 0, open_items = 0;
+    for (;;) {
+        if (open_items == 0) {
+            chunk0 = uni(rk_fetch_chunk(B, n_items, open_items));
+            open_items = uni(open_items);
+            if (chunk0 >= n_items) break;
+            continue;
+        }
+        const uint32_t i = chunk0 + (uint32_t)__builtin_ctz(open_items);
+        open_items &= open_items - 1u;
+        const uint32_t bi = uni(B.rk_list[i]);
+        const uint32_t b = uni(B.bk_list[bi].blk), cnt = uni(B.bk_list[bi].cnt) & 0x7fffffffu;
+        const uint32_t start = uni(B.bk_list[bi].start) & 0x7fffffffu;
+        const uint32_t *__restrict__ isa = rank_array(B, uni(B.blk[b].n_selectors));
+        const uint32_t n = uni(B.blk[b].n);
+        const uint64_t h64 = (uint64_t)uni(B.blk[b].n_mtf) << B.rk_h_shift;
+        if (!isa || h64 >= n) continue;                             // (left to the general sorter: see bzx_launch_brank)
+        const uint32_t h = (uint32_t)h64;
+        uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
+        uint32_t tid = tid_here(), lane = tid & 63u, wave = tid >> 6;
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t p = j * SK_NT + tid;
+            const uint64_t v = p < cnt ? sax[p] : (1ull << 32);
+            s_x[p] = v & 0xFFFFFull;
+            s_w[p] = p;
+            const uint64_t m = __ballot(p >= cnt || ((v >> 32) & 1ull));
+            if (lane == 0) s_f[j * SK_NW + wave] = m;
+        }
+        if (tid == 0) {
+            s_f[BS_FW] = ~0ull;
+            s_rc[0][0] = s_rc[0][1] = s_rc[0][2] = s_rc[0][3] = 0;
+        }
+        __syncthreads();
+        // tied ranks fetch the rank of the rotation h ahead; groups above BS_TINY are listed
+        uint32_t tmask = 0, hmask = 0;
+        uint32_t xa[BS_E];
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t p = j * SK_NT + tid;
+            const uint32_t f0 = p < cnt ? fbit(p) : 1u, f1 = p < cnt ? fbit(p + 1) : 1u;
+            xa[j] = 0;
+            if (!(f0 && f1)) {
+                tmask |= 1u << j;
+                hmask |= f0 << j;
+                uint32_t x = (uint32_t)s_x[p] + h;
+                if (x >= n) x -= n;
+                xa[j] = x;
+            }
+        }
+        uint32_t g[BS_E];
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) g[j] = ((tmask >> j) & 1u) ? isa[xa[j]] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            if ((hmask >> j) & 1u) {
+                const uint32_t p = j * SK_NT + tid;
+                uint32_t wi = p >> 6;
+                uint64_t w = (s_f[wi] >> (p & 63u)) >> 1;
+                uint32_t e;
+                if (w) {
+                    e = p + 1u + (uint32_t)__builtin_ctzll(w);
+                } else {
+                    do w = s_f[++wi]; while (!w);
+                    e = wi * 64 + (uint32_t)__builtin_ctzll(w);
+                }
+                const uint32_t size = e - p;
+                if (size > BS_MED) s_large[atomicAdd(&s_rc[0][2], 1u)] = p | (size << 16);
+                else if (size > BS_TINY) s_med[atomicAdd(&s_rc[0][1], 1u)] = p | (size << 16);
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++)
+            if ((tmask >> j) & 1u) s_w[j * SK_NT + tid] = ((uint64_t)g[j] << 44) | (uint64_t)(j * SK_NT + tid);
+        __syncthreads();
+        const uint32_t nmed = s_rc[0][1], nlarge = s_rc[0][2];
+        if (nmed | nlarge) {
+            for (;;) {
+                uint32_t k = 0;
+                if (lane == 0) k = atomicAdd(&s_rc[0][3], 1u);
+                k = __shfl(k, 0);
+                if (k >= nmed) break;
+                const uint32_t e = s_med[k], gs = e & 0xFFFFu, sz = e >> 16;
+                wave_radix_sort(gs, sz, 48, 64);
+                mark_changes(gs, sz, 48, lane, 64);
+                lds_order();
+                if (__ballot(any_big(gs, sz, lane, 64))) {
+                    wave_radix_sort(gs, sz, 14, 64);
+                    mark_changes(gs, sz, 14, lane, 64);
+                }
+            }
+            for (uint32_t k = 0; k < nlarge; k++) {
+                const uint32_t e = s_large[k], gs = e & 0xFFFFu, sz = e >> 16;
+                wg_radix_sort<1>(gs, sz, 48, 64);
+                mark_changes(gs, sz, 48, tid, SK_NT);
+                if (tid == 0) s_bc[2] = 0;
+                __syncthreads();
+                if (any_big(gs, sz, tid, SK_NT)) s_bc[2] = 1;
+                __syncthreads();
+                if (s_bc[2]) {
+                    wg_radix_sort<1>(gs, sz, 14, 64);
+                    mark_changes(gs, sz, 14, tid, SK_NT);
+                }
+            }
+            __syncthreads();
+        }
+        tid = tid_here();
+        lane = tid & 63u;
+        wave = tid >> 6;
+        // groups of up to BS_TINY ranks: every lane ranks its own word among its group's
+        uint32_t dst_[BS_E];
+        uint64_t my[BS_E];
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            dst_[j] = 0xFFFFFFFFu;
+            my[j] = 0;
+            uint32_t a_ = 0, sz = 0;
+            if ((tmask >> j) & 1u) {
+                const uint32_t p = j * SK_NT + tid;
+                uint32_t e_;
+                if (tiny_bounds(p, a_, e_) && e_ - a_ > 1) {
+                    sz = e_ - a_;
+                    my[j] = s_w[p];
+                }
+            }
+            uint32_t r = 0, eq = 0;
+            for (uint32_t i2 = 0; i2 < sz; i2 += 4) {
+                uint64_t wq[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) wq[k] = s_w[a_ + (i2 + k < sz ? i2 + k : sz - 1)];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const bool lt = i2 + k < sz && wq[k] < my[j];
+                    r += lt;
+                    eq += lt && ((wq[k] ^ my[j]) >> 14) == 0;
+                }
+            }
+            if (sz) dst_[j] = (a_ + r) | (eq ? 0u : 0x80000000u);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            if (dst_[j] != 0xFFFFFFFFu) {
+                const uint32_t q = dst_[j] & 0x7FFFFFFFu;
+                s_w[q] = my[j];
+                if ((dst_[j] >> 31) && !fbit(q)) fset(q);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t p = j * SK_NT + tid;
+            // (bit 33: the rank was tied when the round began -- only those can have a new group head)
+            if (p < cnt)
+                sax[p] = s_x[(uint32_t)(s_w[p] & W_POS_MASK)] | ((uint64_t)fbit(p) << 32) | ((uint64_t)((tmask >> j) & 1u) << 33);
+        }
+        __syncthreads();
+    }
+}
+
+// Every open bucket enters the head rank of each of its groups into the rank array; a bucket whose groups are all
+// single ranks is finished: its part of the last column and the row of rotation 0 are written, and the block leaves
+// the resume state with its last open bucket.
+__global__ __launch_bounds__(SK_NT) void bzx_brank_update_kernel(BzxBatch B)
+{
+    if (B.counters[BZX_CTR_RK_OPEN] == 0) return;
+    const uint32_t n_items = B.counters[BZX_CTR_RK_ITEMS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t chunk0 = 0, open_items = 0;
+    for (;;) {
+        if (open_items == 0) {
+            chunk0 = rk_fetch_chunk(B, n_items, open_items);
+            if (chunk0 >= n_items) break;
+            continue;
+        }
+        const uint32_t i = chunk0 + (uint32_t)__builtin_ctz(open_items);
+        open_items &= open_items - 1u;
+        const uint32_t bi = B.rk_list[i];
+        const uint32_t b = B.bk_list[bi].blk, cnt = B.bk_list[bi].cnt & 0x7fffffffu, start = B.bk_list[bi].start & 0x7fffffffu;
+        uint32_t *__restrict__ isa = rank_array(B, B.blk[b].n_selectors);
+        if (!isa) continue;
+        const uint32_t n = B.blk[b].n;
+        const uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
+        uint32_t rot[BS_E], due = 0;
+        int open = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t p = j * SK_NT + tid;
+            const uint64_t v = p < cnt ? sax[p] : (1ull << 32);
+            rot[j] = (uint32_t)v & 0xFFFFFu;
+            due |= (uint32_t)((v >> 33) & 1ull) << j;
+            const bool f = p >= cnt || ((v >> 32) & 1ull);
+            open |= !f;
+            const uint64_t m = __ballot(f);
+            if (lane == 0) s_f[j * SK_NW + wave] = m;
+        }
+        open = __syncthreads_or(open);
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t p = j * SK_NT + tid;
+            if (p < cnt && ((due >> j) & 1u)) {
+                uint32_t wi = p >> 6;
+                uint64_t w = s_f[wi] & (~0ull >> (63u - (p & 63u)));
+                while (!w) w = s_f[--wi];                          // (rank 0 of the bucket starts a group)
+                isa[rot[j]] = start + wi * 64 + 63u - (uint32_t)__builtin_clzll(w);
+            }
+        }
+        if (!open) {
+            const uint8_t *__restrict__ T = BZX_BLOCK_PTR(B, B.blk[b]);
+            uint8_t *__restrict__ L = B.bwt + BZX_SLAB(B, b) * BZX_BLK_STRIDE + start;
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) {
+                const uint32_t p = j * SK_NT + tid;
+                if (p < cnt) {
+                    L[p] = T[rot[j] ? rot[j] - 1 : n - 1];
+                    if (rot[j] == 0) B.blk[b].orig_ptr = start + p;
+                }
+            }
+            if (tid == 0) {
+                B.bk_list[bi].dbits |= 0x80000000u;
+                atomicSub(&B.counters[BZX_CTR_RK_OPEN], 1u);
+                if (atomicSub(&B.blk[b].n_groups, 1u) == 1u) atomicAnd(&B.blk[b].status, ~BZX_ST_RESUME);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
+#define RK_ROUNDS 14                    // depths h0 .. h0 << 13: enough for give-up depths from 55 symbols on
+
+void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream)
+{
+    BzxBatch R = B;
+    uint32_t launch = 0;
+    auto go = [&](void (*k)(BzxBatch)) {
+        R.rk_fetch = BZX_CTR_RK_FETCH + launch++;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(SK_NT), 0, stream, R);
+    };
+    R.rk_h_shift = 0;
+    go(bzx_brank_update_kernel);
+    for (uint32_t r = 0; r < RK_ROUNDS; r++) {
+        R.rk_h_shift = r;
+        go(bzx_brank_sort_kernel);
+        go(bzx_brank_update_kernel);
+    }
+    static_assert(1 + 2 * RK_ROUNDS <= BZX_N_COUNTERS - BZX_CTR_RK_FETCH, "one fetch counter per launch");
 }
 
 void bzx_launch_bsplit(const BzxBatch &B, uint32_t grid, hipStream_t stream)

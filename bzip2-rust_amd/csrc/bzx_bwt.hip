@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
 {
     unsigned long long t_last = 0;
     const uint32_t tid = threadIdx.x;
-    const BzxSortWs ws = B.sort_ws[blockIdx.x];
+    const BzxSortWs ws = B.sort_ws[blockIdx.x + B.slot_base];
 
     for (;;) {
         if (tid == 0) s_bcast[0] = atomicAdd(&B.counters[B.ctr_bwt], 1u);
@@ -1030,6 +1030,10 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         __syncthreads();
         if (j_ >= (B.redo == 2 ? B.counters[BZX_CTR_RESUME] : B.redo ? B.counters[BZX_CTR_REDO] : B.nblk)) break;
         const uint32_t b = B.redo == 2 ? B.resume_list[j_] : B.redo ? B.redo_list[j_] : B.blk_first + j_ * B.blk_step;
+        if (B.redo == 2 && !(B.blk[b].status & BZX_ST_RESUME)) continue;      // finished by the bucket sorter's rank rounds
+                                                                               // (or by this kernel's early launch)
+        if (B.redo == 2 && B.redo_once == 2 && B.blk[b].n_selectors != 0xFFFFFFFFu) continue;   // early launch: see bzx_device.h
+        if (B.redo == 2 && tid == 0) atomicAdd(&B.counters[BZX_CTR_RESUME_LEFT], 1u);
 
         const uint32_t n = B.blk[b].n;
         const uint8_t *__restrict__ T = BZX_BLOCK_PTR(B, B.blk[b]);
@@ -1208,13 +1212,16 @@ __global__ __launch_bounds__(SORT_NT) void bzx_bwt_kernel(BzxBatch B)
         PHASE_STAMP(3);
         if (DBG_ON && tid == 0) B.blk[b].pad_[1] = (uint32_t)((wall_clock64() - t_blk0) / 100);   // microseconds in this kernel
         if (tid == 0) {
-            B.blk[b].status = (m > 0) ? BZX_ST_PERIODIC : 0u;
+            // (a block sorted from scratch keeps BZX_ST_REDO: the bucket sort kernels, possibly still running beside
+            // this launch, skip whatever buckets the split kernel had emitted for it before it refused the block)
+            B.blk[b].status = ((m > 0) ? BZX_ST_PERIODIC : 0u) | (B.redo == 1 ? BZX_ST_REDO : 0u);
             if (m > 0) {
                 B.blk[b].pad_[0] = s_bcast[3];                       // copies of every rotation (k of u^k)
                 B.plist[atomicAdd(&B.counters[5], 1u)] = b;          // tie order fixed up by bzx_periodic.hip
             }
         }
         __syncthreads();
+        if (B.redo_once == 1) break;
     }
 }
 

@@ -35,6 +35,12 @@
 #define BZX_CTR_REDO_FETCH 12      // blocks fetched by the general sorter in redo mode
 #define BZX_CTR_RESUME 13          // blocks whose leftover groups the general sorter finishes (resume_list)
 #define BZX_CTR_RESUME_FETCH 14
+#define BZX_CTR_RK_ITEMS 32         // buckets that gave up (rk_list), finished by the rank rounds
+#define BZX_CTR_RK_OPEN 33          // ... of which still open
+#define BZX_CTR_RK_FETCH 64         // [64..191] one work-fetch counter per launch of the rank-round kernels
+#define BZX_N_COUNTERS 192
+#define BZX_CTR_RESUME_FETCH2 38     // ... by its early launch (blocks with an oversized bin)
+#define BZX_CTR_RESUME_LEFT 34      // resume blocks the general sorter still had to finish
 #define BZX_CTR_STAT0 16           // [16..31] diagnostics of the bucket sorter (rounds, leftovers, ...)
 
 // One bucket of rotations: ranks [start, start+cnt) of block blk, all sharing the first `dbits` bits; records
@@ -57,8 +63,8 @@ struct BzxBlock {
     uint32_t status;        // BZX_ST_*
     uint32_t n_mtf;         // MTF/RLE2: number of symbols incl. EOB
     uint32_t n_in_use;      // distinct byte values in the block
-    uint32_t n_groups;      // Huffman: coding tables 2..6
-    uint32_t n_selectors;   // ceil(n_mtf / 50)
+    uint32_t n_groups;      // Huffman: coding tables 2..6   (bucket sorter, until then: buckets of the block still open)
+    uint32_t n_selectors;   // ceil(n_mtf / 50)              (bucket sorter, until then: index of the block in resume_list)
     uint64_t bits;          // size of the block image in bits (header .. last payload bit)
     uint64_t out_bit;       // bit position of the block image in the output buffer
     uint32_t sec_bits[4];   // [0] selectors, [1] coding tables, [2] payload, [3] symbol map
@@ -85,7 +91,7 @@ struct BzxBatch {
     uint32_t ctr_bwt;       // index of the block-fetch counter this BWT launch uses (0, or 6 for a concurrent second launch)
     uint32_t ctr_mtf;       // same for the MTF kernel (1 or 7)
     uint32_t packed;        // emit at blk.pack_word (packed per-rank buffer) instead of blk.out_bit (final stream)
-    uint32_t *counters;     // [64] atomic work counters, one per stage kernel (zeroed per batch); [5] = #periodic
+    uint32_t *counters;     // [BZX_N_COUNTERS] atomic work counters, one per stage kernel (zeroed per batch); [5] = #periodic
     uint32_t *plist;        // [nblk] indices of the blocks flagged periodic by the BWT kernel
     const uint8_t *in;      // block slab buffer (RLE1'd bytes), block b at blk[b].in_off
     const uint8_t *raw;     // raw input (blocks on which RLE1 is the identity are read in place)
@@ -108,9 +114,16 @@ struct BzxBatch {
     uint32_t bk_cap;
     uint32_t *redo_list;    // [nblk] blocks for the general sorter
     uint32_t *resume_list;  // [nblk] blocks the general sorter finishes (BZX_ST_RESUME)
+    uint32_t *rk_list;      // [bk_cap] indices into bk_list of the buckets that gave up
+    uint32_t rk_fetch;      // rank rounds: this launch's work-fetch counter (index into counters)
+    uint32_t rk_h_shift;    // rank rounds: this round compares ranks h = (give-up depth of the block) << rk_h_shift symbols ahead
     uint32_t redo;          // general sorter: 1 = sort the blocks of redo_list from scratch; 2 = finish the blocks of resume_list
     uint32_t bsort_mode;    // bucket sort kernel: 0 = sort; 1 = fill pass (write the order of the finished buckets of BZX_ST_RESUME blocks)
     uint32_t n_slots;
+    uint32_t slot_base;     // general sorter: workgroup g works in sort slot slot_base + g
+    uint32_t redo_once;     // general sorter, early launches beside the bucket sorter: 1 = redo mode, every workgroup takes at most one
+                            // block; 2 = resume mode, only the blocks without a rank array (oversized bin)
+    uint32_t rk_slot0;      // rank rounds: first sort slot that holds rank arrays
     uint32_t dbg_stop;       // diagnostics only: leave the BWT kernel after phase k (0 = run everything)
     unsigned long long *dbg; // optional [64] phase timers (100 MHz ticks), null in production
 };

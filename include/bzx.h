@@ -191,7 +191,12 @@ typedef struct {
                                    ran beside the MTF stage on a second stream); ms_bwt covers all of them */
     uint32_t n_redo;            /* blocks the bucket sorter handed to the general sorter (deep repeats, periodic) */
     uint32_t n_buckets;         /* bucket work items of the bucket sorter */
-    float ms_bwt_split, ms_bwt_sort, ms_bwt_general;   /* parts of ms_bwt: split kernel, bucket sort kernel, general sorter + periodic */
+    float ms_bwt_split, ms_bwt_sort, ms_bwt_general;   /* parts of ms_bwt: split kernel, bucket sort kernel, everything after it */
+    uint32_t n_open_buckets;      /* buckets that gave up after the refinement rounds (deep repeats) */
+    uint32_t n_open_left;         /* ... still open after the rank rounds (left to the general sorter) */
+    uint32_t n_resume_left;       /* blocks the general sorter had to finish */
+    float ms_bwt_rank;            /* part of ms_bwt_general: rank rounds over the open buckets */
+    uint32_t n_from_scratch;      /* blocks the split kernel refused (sorted from scratch by the general sorter) */
 } bzx_stats;
 int bzx_get_stats(const bzx_ctx *ctx, bzx_stats *out);
 

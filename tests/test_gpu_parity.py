@@ -312,6 +312,29 @@ def test_large_roundtrip_properties(bzx, oracle):
     assert out[: len(ref) - 300_000] == ref[: len(ref) - 300_000]
 
 
+def test_leftover_groups_paths(bzx, oracle):
+    """The three ways a block's deep repeats are finished, each checked to be the one taken: (a) duplicated files in
+    text -- buckets give up, the grid-wide rank rounds close all of them; (b) thousands of rotations sharing a long
+    prefix -- an oversized bin is left as one group and the general sorter finishes the block; (c) a block that is a
+    whole number of copies of a unit -- refused by the split kernel, sorted from scratch, flagged periodic."""
+    big = oracle.synthtext(900_000)
+    dup = big[:400_000] + big[100_000:180_000] + big[400_000:700_000] + big[120_000:150_000] + b"!"
+    out = bzx.compress_buffer(dup, 9)
+    st = bzx.stats()
+    assert out == bz2.compress(dup, 9)
+    assert st.n_open_buckets > 0 and st.n_open_left == 0 and st.n_resume_left == 0 and st.n_from_scratch == 0
+    runs = big[:300_000] + (b"ab" * 700 + b"c") * 200 + big[300_000:500_000] + b"?"
+    out = bzx.compress_buffer(runs, 9)
+    st = bzx.stats()
+    assert out == bz2.compress(runs, 9)
+    assert st.n_resume_left == 1 and st.n_from_scratch == 0
+    per = oracle.synthtext(90_000) * 5
+    out = bzx.compress_buffer(per, 9)
+    st = bzx.stats()
+    assert out == bz2.compress(per, 9)
+    assert st.n_from_scratch == 1 and st.n_periodic == 1
+
+
 def test_deep_repeats(bzx, oracle):
     """Highly redundant blocks (near-identical copies, fixed-size records): large groups that single symbols do
     not separate are frozen and finished by prefix doubling; the stream must still be libbz2's bit for bit."""
