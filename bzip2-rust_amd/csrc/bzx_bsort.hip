@@ -744,7 +744,7 @@ __device__ __forceinline__ uint32_t *rank_array(const BzxBatch &B, uint32_t k)
 #ifndef SK_WAVES_PER_SIMD
 #define SK_WAVES_PER_SIMD 4             // 128 VGPRs: no spills (at 80 the round loop spills ~40 registers to scratch)
 #endif
-__global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(BzxBatch B)
+__device__ __forceinline__ void bsort_body(const BzxBatch &B)
 {
     const uint32_t tid0 = threadIdx.x;
     const uint32_t n_items = B.counters[BZX_CTR_BK_ITEMS] < B.bk_cap ? B.counters[BZX_CTR_BK_ITEMS] : B.bk_cap;
@@ -1026,6 +1026,10 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(Bzx
     DIAG_FLUSH();
 }
 
+// (two names for one body: profiles list the sort proper and the fill pass -- a no-op launch unless a block has a
+// bucket that gave up -- separately)
+__global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(BzxBatch B) { bsort_body(B); }
+__global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bfill_kernel(BzxBatch B) { bsort_body(B); }
 
 // ---- rank rounds: the buckets that gave up, finished by prefix doubling ---------------------------------------
 // A bucket gives up when some of its rotations still agree after BS_ROUNDS refinement rounds (deep repeats).  Its
@@ -1323,7 +1327,8 @@ void bzx_launch_bsplit(const BzxBatch &B, uint32_t grid, hipStream_t stream)
 
 void bzx_launch_bsort(const BzxBatch &B, uint32_t grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL(bzx_bsort_kernel, dim3(grid), dim3(SK_NT), 0, stream, B);
+    if (B.bsort_mode == 1) hipLaunchKernelGGL(bzx_bfill_kernel, dim3(grid), dim3(SK_NT), 0, stream, B);
+    else hipLaunchKernelGGL(bzx_bsort_kernel, dim3(grid), dim3(SK_NT), 0, stream, B);
 }
 
 uint32_t bzx_bsort_blocks_per_cu()
