@@ -22,6 +22,7 @@ void bzx_launch_bwt(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_bsplit(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_bsort(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream);
+void bzx_launch_pack_max(const BzxBatch &B, uint32_t world, uint64_t *d_out, hipStream_t stream);
 void bzx_launch_periodic(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_mtf(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_huffman(const BzxBatch &B, uint32_t grid, hipStream_t stream);
@@ -111,6 +112,7 @@ struct bzx_ctx {
     // sharded run state (bzx_shard_prepare -> bzx_shard_emit)
     uint32_t shard_total = 0, shard_rank = 0, shard_world = 1;
     int shard_level = 0;
+    uint64_t shard_packed_max = 0;   // bytes of the longest packed buffer of any rank (known after bzx_shard_emit_packed)
     size_t shard_len = 0;
 
     struct bzx_cstream *cs = nullptr;        // chunked stream compressor kept for bzx_compress_buffer
@@ -1071,6 +1073,7 @@ extern "C" int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, in
     ctx->shard_rank = rank;
     ctx->shard_world = world;
     ctx->shard_level = level;
+    ctx->shard_packed_max = 0;
     ctx->shard_len = len;
     *nblk_total = nblk;
     return BZX_OK;
@@ -1091,6 +1094,16 @@ static uint32_t shard_count(uint32_t nblk, uint32_t rank, uint32_t world)
     return nblk > rank ? (nblk - rank + world - 1) / world : 0;
 }
 
+extern "C" int bzx_shard_packed_max(bzx_ctx *ctx, size_t *max_len)
+{
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
+    if (!ctx || !max_len) return BZX_E_PARAM;
+    if (ctx->shard_level == 0 || ctx->shard_packed_max == 0) return BZX_E_STATE;
+    *max_len = (size_t)ctx->shard_packed_max;
+    return BZX_OK;
+}
+
 extern "C" int bzx_shard_emit_packed(bzx_ctx *ctx, const long long *d_bits_all, void *d_packed, size_t cap,
                                      size_t *packed_len, size_t *stream_len)
 {
@@ -1109,8 +1122,10 @@ extern "C" int bzx_shard_emit_packed(bzx_ctx *ctx, const long long *d_bits_all, 
     if (nblk) bzx_launch_bits_import(B, d_bits_all, ctx->stream);
     bzx_launch_layout(B, 32, 0, ctx->d_scalars, ctx->stream);                              // final positions of ALL blocks
     bzx_launch_pack_layout(B, rank, world, mine, ctx->d_scalars + 2, ctx->stream);         // my packed positions
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (world <= 64) bzx_launch_pack_max(B, world, ctx->d_scalars + 3, ctx->stream);       // ... and the longest of any rank
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->shard_packed_max = world <= 64 ? ctx->h_scalars[3] * 4 : 0;
     const uint64_t out_bytes = (ctx->h_scalars[0] + 80 + 7) >> 3;
     const uint64_t need = ctx->h_scalars[2] * 4;
     if (need > cap) {

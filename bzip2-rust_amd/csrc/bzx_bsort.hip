@@ -54,6 +54,9 @@
 #ifndef BS_ROUNDS
 #define BS_ROUNDS 5                     // refinement rounds of 50 bits before a bucket gives up (47 + 400 bits)
 #endif
+#ifndef BS_KEYBITS
+#define BS_KEYBITS 32                   // leading bits of the 32-bit record key sorted by the initial LSD passes (a multiple of 8)
+#endif
 #define BS_TINY 64                      // groups up to this size are ranked by counting
 #define BS_MED 512                      // ... up to this size by one wave
 #define REC_IDX(r) ((uint32_t)((r) >> 12) & 0xFFFFFu)
@@ -802,14 +805,14 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
         }
         if (tid == 0) s_rc[0][0] = s_rc[0][1] = s_rc[0][2] = s_rc[0][3] = 0;
         DIAG_STAMP(65);
-        wg_radix_sort<0>(0, cnt, 32, 64);          // (its first barrier also publishes s_x)
+        wg_radix_sort<0>(0, cnt, 64 - BS_KEYBITS, 64);          // (its first barrier also publishes s_x)
         DIAG_STAMP(66);
         // rank p holds record p; group starts: the 32 key bits differ from the predecessor's
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++) {
             const uint32_t p = j * SK_NT + tid;
             s_w[p] = p;
-            const bool f = p >= cnt || p == 0 || (uint32_t)(s_x[p] >> 32) != (uint32_t)(s_x[p - 1] >> 32);
+            const bool f = p >= cnt || p == 0 || (s_x[p] >> (64 - BS_KEYBITS)) != (s_x[p - 1] >> (64 - BS_KEYBITS));
             const uint64_t m = __ballot(f);
             if (lane == 0) s_f[j * SK_NW + wave] = m;
         }
@@ -817,7 +820,7 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
         __syncthreads();
         DIAG_STAMP(67);
 
-        uint32_t dcur = depth0 + 32;
+        uint32_t dcur = depth0 + BS_KEYBITS;
         bool fail = false;
         for (uint32_t round = 0;; round++) {
             tid = tid_here();

@@ -385,6 +385,24 @@ __global__ __launch_bounds__(EMIT_NT) void bzx_pack_layout_kernel(BzxBatch B, ui
     if (tid == 0) total[0] = l_carry;
 }
 
+// Largest packed buffer of any rank, in words (every rank knows every block's size and position after the exchange
+// of sizes, so the common length of the gather needs no further collective and no extra host round trip).
+__global__ __launch_bounds__(EMIT_NT) void bzx_pack_max_kernel(BzxBatch B, uint32_t world, uint64_t *out)
+{
+    __shared__ unsigned long long sums[64];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 64) sums[tid] = 0;
+    __syncthreads();
+    for (uint32_t b = tid; b < B.nblk; b += EMIT_NT)
+        atomicAdd(&sums[b % world], (unsigned long long)(((B.blk[b].out_bit & 31u) + B.blk[b].bits + 31u) >> 5));
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long m = 0;
+        for (uint32_t r = 0; r < world && r < 64; r++) m = sums[r] > m ? sums[r] : m;
+        out[0] = m;
+    }
+}
+
 // Merge one rank's packed buffer into the final stream: interior words are owned by one block, the first and
 // last word of an image may be shared with its neighbours and are OR-ed into the zeroed buffer.
 __global__ __launch_bounds__(256) void bzx_unpack_kernel(BzxBatch B, const uint32_t *__restrict__ packed, uint32_t first,
@@ -432,6 +450,10 @@ void bzx_launch_pack_layout(const BzxBatch &B, uint32_t first, uint32_t step, ui
                             hipStream_t stream)
 {
     hipLaunchKernelGGL(bzx_pack_layout_kernel, dim3(1), dim3(EMIT_NT), 0, stream, B, first, step, nown, d_total);
+}
+void bzx_launch_pack_max(const BzxBatch &B, uint32_t world, uint64_t *d_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_pack_max_kernel, dim3(1), dim3(EMIT_NT), 0, stream, B, world, d_out);
 }
 void bzx_launch_unpack(const BzxBatch &B, const uint32_t *packed, uint32_t first, uint32_t step, uint32_t nown,
                        uint32_t grid, hipStream_t stream)

@@ -130,6 +130,9 @@ int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, int level, ui
                       uint32_t *nblk_total, long long *d_bits, size_t bits_cap);
 int bzx_shard_emit_packed(bzx_ctx *ctx, const long long *d_bits_all, void *d_packed, size_t cap, size_t *packed_len,
                           size_t *stream_len);
+/* After bzx_shard_emit_packed: bytes of the longest packed buffer of any rank -- the common length a gather needs --
+ * computed from the sizes every rank already holds: no further collective, no extra host round trip (world <= 64). */
+int bzx_shard_packed_max(bzx_ctx *ctx, size_t *max_len);
 int bzx_shard_assemble_begin(bzx_ctx *ctx, void *d_out, size_t cap, size_t *stream_len);
 int bzx_shard_assemble_rank(bzx_ctx *ctx, const void *d_packed_r, uint32_t r, void *d_out);
 /* bzx_shard_assemble_* only enqueue work on the context's stream; wait for it here (or on the caller's stream). */

@@ -57,9 +57,15 @@ def main():
     pl, sl = C.c_size_t(), C.c_size_t()
     lib._check(L.bzx_shard_emit_packed(lib.ctx, bits.data_ptr(), packed.data_ptr(), cap, C.byref(pl), C.byref(sl)))
     assert pl.value % 4 == 0
+    # the common length of the gather: the library knows the longest packed buffer of any rank from the sizes;
+    # checked here against the collective it replaces
+    L.bzx_shard_packed_max.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    pm = C.c_size_t()
+    lib._check(L.bzx_shard_packed_max(lib.ctx, C.byref(pm)))
     pmax = torch.tensor([pl.value], dtype=torch.int64)
     dist.all_reduce(pmax, op=dist.ReduceOp.MAX)
-    n4 = int(pmax.item()) // 4
+    assert pm.value == int(pmax.item()), (pm.value, int(pmax.item()))
+    n4 = pm.value // 4
     parts = [torch.zeros(n4, dtype=torch.int32) for _ in range(world)] if rank == 0 else None
     dist.gather(packed[:n4].contiguous(), parts, dst=0)      # every compressed byte travels once
     if rank == 0:
