@@ -353,6 +353,28 @@ extern "C" int bzx_get_stats(const bzx_ctx *ctx, bzx_stats *out)
     return BZX_OK;
 }
 
+extern "C" int bzx_get_block_info(const bzx_ctx *ctx, uint32_t block, bzx_block_info *out)
+{
+    if (!ctx || !out) return BZX_E_PARAM;
+    std::unique_lock<std::recursive_mutex> api_lock_(const_cast<bzx_ctx *>(ctx)->api_mu);
+    if (!ctx->h_blk || block >= ctx->stats.nblk || block >= ctx->cap_blocks) return BZX_E_PARAM;
+    const BzxBlock &d = ctx->h_blk[block];
+    out->n = d.n;
+    out->crc = d.crc;
+    out->orig_ptr = d.orig_ptr;
+    out->periodic = (d.status & BZX_ST_PERIODIC) ? 1u : 0u;
+    out->n_in_use = d.n_in_use;
+    out->n_mtf = d.n_mtf;
+    out->n_tables = d.n_groups;
+    out->n_selectors = d.n_selectors;
+    out->bits_selectors = d.sec_bits[0];
+    out->bits_tables = d.sec_bits[1];
+    out->bits_payload = d.sec_bits[2];
+    out->bits_symbol_map = d.sec_bits[3];
+    out->bits = d.bits;
+    return BZX_OK;
+}
+
 // Number of workgroups for a one-workgroup-per-block kernel over nblk blocks.
 static uint32_t grid_for(const bzx_ctx *ctx, uint32_t nblk, uint32_t per_cu)
 {
@@ -1626,6 +1648,8 @@ static int cstream_collect(bzx_cstream *s)
         s->st_rle1 += d.n;
         s->st_mtf += d.n_mtf;
         s->st_per += (d.status & BZX_ST_PERIODIC) ? 1u : 0u;
+        // (bzx_get_block_info: the stream's descriptors in order, as far as the context's descriptor table reaches)
+        if (ctx->h_blk && s->nblk_total + b < ctx->cap_blocks) ctx->h_blk[s->nblk_total + b] = d;
     }
     s->nblk_total += s->pend_nblk;
     s->bits += cbits;

@@ -204,6 +204,26 @@ typedef struct {
 int bzx_get_stats(const bzx_ctx *ctx, bzx_stats *out);
 
 /*
+ * Per-block figures of the last bzx_compress_device / bzx_compress_buffer / bzx_cstream_* / bzx_compress_block(s)
+ * call, blocks in stream order (a chunked stream: as many as the context's descriptor table holds, i.e. at least
+ * the max_blocks of bzx_ctx_create; BZX_E_PARAM beyond) -- what the reference logs per block at -vvv
+ * (src/compression/compress_block.rs:58-63, src/huffman_coding/huffman.rs:176-181).
+ */
+typedef struct bzx_block_info {
+    uint32_t n;               /* RLE1'd bytes in the block */
+    uint32_t crc;             /* CRC-32/BZIP2 of the raw bytes it covers */
+    uint32_t orig_ptr;        /* BWT: row of rotation 0 */
+    uint32_t periodic;        /* 1: the block is u^k (tie order from the libbz2 replay) */
+    uint32_t n_in_use;        /* distinct byte values */
+    uint32_t n_mtf;           /* MTF/RLE2 symbols incl. EOB */
+    uint32_t n_tables;        /* Huffman coding tables, 2..6 */
+    uint32_t n_selectors;
+    uint32_t bits_symbol_map, bits_selectors, bits_tables, bits_payload;
+    uint64_t bits;            /* size of the block image (header .. last payload bit) */
+} bzx_block_info;
+int bzx_get_block_info(const bzx_ctx *ctx, uint32_t block, bzx_block_info *out);
+
+/*
  * Stream assembler (replaces BitWriter, bitwriter.rs:42-172): header "BZh<level>", bit-granular
  * append of block images minus their padding, footer magic + combined CRC (crc.rs:25-27).
  * Host-side; used with bzx_compress_block(s) when the caller keeps the reference's structure.

@@ -25,6 +25,13 @@ class BzxStats(C.Structure):
                 ("ms_bwt_rank", C.c_float), ("n_from_scratch", C.c_uint32)]
 
 
+class BzxBlockInfo(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("crc", C.c_uint32), ("orig_ptr", C.c_uint32), ("periodic", C.c_uint32),
+                ("n_in_use", C.c_uint32), ("n_mtf", C.c_uint32), ("n_tables", C.c_uint32), ("n_selectors", C.c_uint32),
+                ("bits_symbol_map", C.c_uint32), ("bits_selectors", C.c_uint32), ("bits_tables", C.c_uint32),
+                ("bits_payload", C.c_uint32), ("bits", C.c_uint64)]
+
+
 class BzxError(RuntimeError):
     pass
 
@@ -221,6 +228,12 @@ class BzxLib:
                 continue
             self._check(rc)
             return out.raw[:ol.value]
+
+    def block_info(self, i):
+        bi = BzxBlockInfo()
+        self.lib.bzx_get_block_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(BzxBlockInfo)]
+        self._check(self.lib.bzx_get_block_info(self.ctx, i, C.byref(bi)))
+        return bi
 
     def stats(self):
         st = BzxStats()

@@ -62,6 +62,27 @@ def test_emu_many_groups_per_tile(emu, oracle):
     assert (L, orig) == oracle.bwt(blk)
 
 
+def test_emu_block_info(emu, oracle):
+    """bzx_get_block_info: the per-block figures the reference logs at -vvv (compress_block.rs:58-63,
+    huffman.rs:176-181), against the oracle's stages block by block."""
+    data = oracle.synthtext(120_000) + b"\0" * 3000 + bytes(range(256)) * 40
+    out = emu.compress_buffer(data, 1)
+    assert out == bz2.compress(data, 1)
+    blocks = oracle.split_rle1(data, 1)
+    assert emu.stats().nblk == len(blocks)
+    total = 0
+    for i, (img, crc) in enumerate(blocks):
+        bi = emu.block_info(i)
+        L, orig = oracle.bwt(img)
+        mo, fo, iuo, niu = oracle.mtf(L)
+        hf = oracle.huff(mo, fo, niu + 2)
+        assert (bi.n, bi.crc, bi.orig_ptr, bi.n_in_use, bi.n_mtf) == (len(img), crc, orig, niu, len(mo)), i
+        assert bi.n_tables == hf[0] and bi.n_selectors == len(hf[1]), i
+        assert bi.bits == 48 + 32 + 1 + 24 + bi.bits_symbol_map + 3 + 15 + bi.bits_selectors + bi.bits_tables + bi.bits_payload
+        total += bi.bits
+    assert (32 + total + 80 + 7) // 8 == len(out)
+
+
 def test_emu_leftover_groups_paths(emu, oracle):
     """Deep repeats: buckets that give up and are closed by the rank rounds; an oversized bin left as one group for the
     general sorter; a periodic block sorted from scratch (the paths are asserted, as in the device test)."""

@@ -312,6 +312,27 @@ def test_large_roundtrip_properties(bzx, oracle):
     assert out[: len(ref) - 300_000] == ref[: len(ref) - 300_000]
 
 
+def test_block_info(bzx, oracle):
+    """bzx_get_block_info: the per-block figures the reference logs at -vvv (compress_block.rs:58-63,
+    huffman.rs:176-181), against the oracle's stages block by block."""
+    data = oracle.synthtext(250_000) + b"\0" * 3000 + bytes(range(256)) * 40
+    out = bzx.compress_buffer(data, 1)
+    assert out == bz2.compress(data, 1)
+    blocks = oracle.split_rle1(data, 1)
+    assert bzx.stats().nblk == len(blocks)
+    total = 0
+    for i, (img, crc) in enumerate(blocks):
+        bi = bzx.block_info(i)
+        L, orig = oracle.bwt(img)
+        mo, fo, iuo, niu = oracle.mtf(L)
+        hf = oracle.huff(mo, fo, niu + 2)
+        assert (bi.n, bi.crc, bi.orig_ptr, bi.n_in_use, bi.n_mtf) == (len(img), crc, orig, niu, len(mo)), i
+        assert bi.n_tables == hf[0] and bi.n_selectors == len(hf[1]), i
+        assert bi.bits == 48 + 32 + 1 + 24 + bi.bits_symbol_map + 3 + 15 + bi.bits_selectors + bi.bits_tables + bi.bits_payload
+        total += bi.bits
+    assert (32 + total + 80 + 7) // 8 == len(out)
+
+
 def test_leftover_groups_paths(bzx, oracle):
     """The three ways a block's deep repeats are finished, each checked to be the one taken: (a) duplicated files in
     text -- buckets give up, the grid-wide rank rounds close all of them; (b) thousands of rotations sharing a long

@@ -100,6 +100,14 @@ static int do_zip(const Opts &o, bzx_ctx *ctx, FILE *in, FILE *out, const char *
         bzx_get_stats(ctx, &st);
         fprintf(stderr, "  %s: %zu -> %zu bytes, %.3f:1, %u blocks (%u periodic)\n", name, total_in, produced,
                 produced ? (double)total_in / (double)produced : 0.0, st.nblk, st.n_periodic);
+        // -vv: one line per block, the figures the reference logs at -vvv (compress_block.rs:58-63, huffman.rs:176-181)
+        bzx_block_info bi;
+        for (uint32_t b = 0; o.verbose > 1 && b < st.nblk && bzx_get_block_info(ctx, b, &bi) == BZX_OK; b++)
+            fprintf(stderr, "    block %u: crc = 0x%08x, %u in block, origPtr %u%s, %u values in use, %u mtf symbols, "
+                            "%u coding tables, %u selectors; bits: map %u + selectors %u + tables %u + codes %u -> %llu\n",
+                    b + 1, bi.crc, bi.n, bi.orig_ptr, bi.periodic ? " (periodic)" : "", bi.n_in_use, bi.n_mtf, bi.n_tables,
+                    bi.n_selectors, bi.bits_symbol_map, bi.bits_selectors, bi.bits_tables, bi.bits_payload,
+                    (unsigned long long)bi.bits);
     }
     bzx_cstream_end(cs);
     bzx_host_free(buf[0]);
