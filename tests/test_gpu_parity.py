@@ -344,7 +344,7 @@ def test_leftover_groups_paths(bzx, oracle):
     st = bzx.stats()
     assert out == bz2.compress(dup, 9)
     assert st.n_open_buckets > 0 and st.n_open_left == 0 and st.n_resume_left == 0 and st.n_from_scratch == 0
-    runs = big[:300_000] + (b"ab" * 700 + b"c") * 200 + big[300_000:500_000] + b"?"
+    runs = big[:120_000] + (b"ab" * 700 + b"c") * 200 + big[120_000:200_000] + b"?"
     out = bzx.compress_buffer(runs, 9)
     st = bzx.stats()
     assert out == bz2.compress(runs, 9)
@@ -353,7 +353,12 @@ def test_leftover_groups_paths(bzx, oracle):
     out = bzx.compress_buffer(per, 9)
     st = bzx.stats()
     assert out == bz2.compress(per, 9)
-    assert st.n_from_scratch == 1 and st.n_periodic == 1
+    assert st.n_periodic == 1 and st.n_resume_left == 1 and st.n_from_scratch == 0
+    tiny = b"abcabcabd" * 5
+    out = bzx.compress_buffer(tiny, 9)
+    st = bzx.stats()
+    assert out == bz2.compress(tiny, 9)
+    assert st.n_periodic == 1 and st.n_resume_left == 1
 
 
 def test_deep_repeats(bzx, oracle):
