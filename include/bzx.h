@@ -103,8 +103,9 @@ int bzx_split_rle1(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level, uint
  * minus file I/O).  d_raw / d_out are DEVICE pointers (HBM); nothing but the final length
  * crosses PCIe.  cap >= len + len/50 + 4096.  Alignment: d_raw 16 bytes, d_out 4 bytes (BZX_E_PARAM otherwise,
  * with the reason in bzx_last_error): a view into a larger device tensor must start on such a boundary.
- * Cost cliff: blocks that are an exact power u^k (inputs made of one repeated byte and the like)
- * need libbz2's tie order among identical rotations and take ~2 s each instead of milliseconds.
+ * Cost: blocks that are an exact power u^k (inputs made of one repeated byte and the like) need
+ * libbz2's tie order among identical rotations: ~0.1 s for an all-zero block (many copies of a long unit: seconds)
+ * instead of milliseconds; such blocks of one call are handled side by side.
  */
 int bzx_compress_device(bzx_ctx *ctx, const void *d_raw, size_t len, int level, void *d_out, size_t cap,
                         size_t *out_len);
