@@ -1094,10 +1094,12 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_sort_kerne
         const uint32_t h = (uint32_t)h64;
         uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
         uint32_t tid = tid_here(), lane = tid & 63u, wave = tid >> 6;
+        uint32_t was_due = 0;                                       // bit j: the entry of row j carries a "due" mark
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++) {
             const uint32_t p = j * SK_NT + tid;
             const uint64_t v = p < cnt ? sax[p] : (1ull << 32);
+            was_due |= (uint32_t)((v >> 33) & 1ull) << j;
             s_x[p] = v & 0xFFFFFull;
             s_w[p] = p;
             const uint64_t m = __ballot(p >= cnt || ((v >> 32) & 1ull));
@@ -1226,8 +1228,9 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_sort_kerne
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++) {
             const uint32_t p = j * SK_NT + tid;
-            // (bit 33: the rank was tied when the round began -- only those can have a new group head)
-            if (p < cnt)
+            // (bit 33: the rank was tied when the round began -- only those can have a new group head.  Ranks that were
+            // not tied keep their occupant and their flag: they are stored only to clear a mark left by an earlier round)
+            if (p < cnt && (((tmask | was_due) >> j) & 1u))
                 sax[p] = s_x[(uint32_t)(s_w[p] & W_POS_MASK)] | ((uint64_t)fbit(p) << 32) | ((uint64_t)((tmask >> j) & 1u) << 33);
         }
         __syncthreads();
