@@ -1,3 +1,5 @@
+"""Ad-hoc GPU probe: the near-periodic tail block of an all-zero input, a 64 MiB zero buffer end to end, and (BZX_LIB=...libbzx_diag.so)
+the phase split of the periodic kernel; run it under `timeout`."""
 import sys, time
 sys.path.insert(0, "tests")
 from bzx_ctypes import *
