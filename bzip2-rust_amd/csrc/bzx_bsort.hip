@@ -883,7 +883,7 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
             __syncthreads();
             DIAG_STAMP(68);
             if (s_rc[par][0] == 0) break;
-            if (!can) {                                            // deep repeats / identical rotations: general sorter
+            if (!can) {                                            // deep repeats / identical rotations: rank rounds
                 DIAG_COUNT(round >= BS_ROUNDS ? 84 : 85, 1);
                 fail = true;
                 break;
@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_sort_kerne
 }
 
 // Every open bucket enters the head rank of each of its groups into the rank array; a bucket whose groups are all
-// single ranks is finished: its part of the last column and the row of rotation 0 are written, and the block leaves
+// single ranks is finished: its rows of the last column and the row of rotation 0 are written, and the block leaves
 // the resume state with its last open bucket.
 __global__ __launch_bounds__(SK_NT) void bzx_brank_update_kernel(BzxBatch B)
 {
@@ -1274,6 +1274,7 @@ __global__ __launch_bounds__(SK_NT) void bzx_brank_update_kernel(BzxBatch B)
             if (lane == 0) s_f[j * SK_NW + wave] = m;
         }
         open = __syncthreads_or(open);
+        // ranks that were tied when the round began: new group head into the rank array
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++) {
             const uint32_t p = j * SK_NT + tid;
@@ -1284,7 +1285,10 @@ __global__ __launch_bounds__(SK_NT) void bzx_brank_update_kernel(BzxBatch B)
                 isa[rot[j]] = start + wi * 64 + 63u - (uint32_t)__builtin_clzll(w);
             }
         }
-        if (!open) {
+        // The bucket's rows of the last column, when it is finished -- and in the last launch for a bucket that is
+        // still open: it goes to the general sorter, which rewrites only the ranks that are still tied then, not the
+        // ones these rounds resolved and moved.
+        if (!open || B.rk_last) {
             const uint8_t *__restrict__ T = BZX_BLOCK_PTR(B, B.blk[b]);
             uint8_t *__restrict__ L = B.bwt + BZX_SLAB(B, b) * BZX_BLK_STRIDE + start;
 #pragma unroll
@@ -1295,6 +1299,8 @@ __global__ __launch_bounds__(SK_NT) void bzx_brank_update_kernel(BzxBatch B)
                     if (rot[j] == 0) B.blk[b].orig_ptr = start + p;
                 }
             }
+        }
+        if (!open) {
             if (tid == 0) {
                 B.bk_list[bi].dbits |= 0x80000000u;
                 atomicSub(&B.counters[BZX_CTR_RK_OPEN], 1u);
@@ -1306,7 +1312,9 @@ __global__ __launch_bounds__(SK_NT) void bzx_brank_update_kernel(BzxBatch B)
 }
 
 
+#ifndef RK_ROUNDS
 #define RK_ROUNDS 14                    // depths h0 .. h0 << 13: enough for give-up depths from 55 symbols on
+#endif
 
 void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream)
 {
@@ -1317,10 +1325,12 @@ void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream)
         hipLaunchKernelGGL(k, dim3(grid), dim3(SK_NT), 0, stream, R);
     };
     R.rk_h_shift = 0;
+    R.rk_last = 0;
     go(bzx_brank_update_kernel);
     for (uint32_t r = 0; r < RK_ROUNDS; r++) {
         R.rk_h_shift = r;
         go(bzx_brank_sort_kernel);
+        R.rk_last = r + 1 == RK_ROUNDS;
         go(bzx_brank_update_kernel);
     }
     static_assert(1 + 2 * RK_ROUNDS <= BZX_N_COUNTERS - BZX_CTR_RK_FETCH, "one fetch counter per launch");

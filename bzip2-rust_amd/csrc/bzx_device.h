@@ -116,6 +116,7 @@ struct BzxBatch {
     uint32_t *resume_list;  // [nblk] blocks the general sorter finishes (BZX_ST_RESUME)
     uint32_t *rk_list;      // [bk_cap] indices into bk_list of the buckets that gave up
     uint32_t rk_fetch;      // rank rounds: this launch's work-fetch counter (index into counters)
+    uint32_t rk_last;       // rank rounds: this is the last update launch
     uint32_t rk_h_shift;    // rank rounds: this round compares ranks h = (give-up depth of the block) << rk_h_shift symbols ahead
     uint32_t redo;          // general sorter: 1 = sort the blocks of redo_list from scratch; 2 = finish the blocks of resume_list
     uint32_t bsort_mode;    // bucket sort kernel: 0 = sort; 1 = fill pass (write the order of the finished buckets of BZX_ST_RESUME blocks)

@@ -83,6 +83,31 @@ def test_emu_block_info(emu, oracle):
     assert (32 + total + 80 + 7) // 8 == len(out)
 
 
+def test_emu_short_rank_rounds(emu, oracle):
+    """Buckets that are still open after the rank rounds although the rounds resolved (and moved) some of their ranks:
+    the general sorter finishes the block and every row of the last column must be current.  Built with two rank
+    rounds instead of fourteen (tests/emu/build_emu.sh) so that repeats of a few hundred symbols get there: three
+    copies of a 600-symbol stretch stay tied, three copies of its first 120 symbols -- different bytes before and after
+    each -- are separated from them in the rounds."""
+    lib = BzxLib(EMU_PATH.replace("libbzx_emu.so", "libbzx_emu_rk2.so"))
+    try:
+        for seed in range(3):
+            rnd = random.Random(seed)
+            d = oracle.synthtext(4000)
+            m, s = d[300:900], d[300:420]
+            parts = [d]
+            for i in range(3):
+                parts += [b"QZA"[i:i + 1], m, bytes([rnd.randrange(1, 30)])]
+            for i in range(3):
+                parts += [b"KBX"[i:i + 1], s, bytes([rnd.randrange(1, 30)]), d[rnd.randrange(1000, 3000):][:50]]
+            blk = b"".join(parts)
+            assert lib.compress_buffer(blk, 9) == bz2.compress(blk, 9), seed
+            st = lib.stats()
+            assert st.n_open_left > 0 and st.n_resume_left == 1 and st.n_periodic == 0
+    finally:
+        lib.close()
+
+
 def test_emu_leftover_groups_paths(emu, oracle):
     """Deep repeats: buckets that give up and are closed by the rank rounds; an oversized bin left as one group for the
     general sorter; a periodic block sorted from scratch (the paths are asserted, as in the device test)."""
