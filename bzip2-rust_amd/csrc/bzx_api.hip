@@ -421,6 +421,9 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         const bool early = ctx->n_slots >= 64;
         const uint32_t n_early = 32;
         B.rk_slot0 = early ? n_early : 0;
+#ifdef BZX_STRESS_FEW_RANK_ARRAYS                                   // (stress builds: only eight blocks get a rank array)
+        B.rk_slot0 = ctx->n_slots - 1;
+#endif
         B.slot_base = 0;
         B.redo_once = 0;
         if (early) {

@@ -43,7 +43,9 @@
 #define BS_NBIN1 (1u << BS_BIN1)
 #define BS_TAB_WORDS (BS_NBIN1 + (BS_NBIN1 >> 5))
 #define BS_MAX_BK 1024                   // buckets one split (one level of one range) may produce
+#ifndef BS_MAX_BIG
 #define BS_MAX_BIG 512                  // oversized bins waiting for a deeper split at any one time (ring, per block)
+#endif
 #define SP_U 4                          // split kernel: groups of four rotations in flight per lane
 #ifndef BS_MAX_DEPTH
 #define BS_MAX_DEPTH 511                // deepest split: 15 + 41 x 12 key bits ...
