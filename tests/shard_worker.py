@@ -27,6 +27,12 @@ def main():
         # zeros (one long run across several blocks' worth of input), then runs of 1..600, then text
         mix = b"\0" * (nbytes // 3) + make_input(o, {"kind": "runs", "n": nbytes // 3, "seed": 5}) + o.synthtext(nbytes // 3)
         data = np.frombuffer(mix, dtype=np.uint8).copy()
+    elif kind == "dups":
+        # duplicated stretches inside and across blocks: buckets give up, the fill pass and the rank rounds run on
+        # descriptors indexed by the global block number and slabs indexed by the local one
+        t = o.synthtext(nbytes // 2)
+        mix = t[: nbytes // 4] + t[1000:40000] + t[nbytes // 4:] + t[2000:30000] + t[: nbytes // 3]
+        data = np.frombuffer(mix[:nbytes], dtype=np.uint8).copy()
     else:
         data = np.frombuffer(o.synthtext(nbytes), dtype=np.uint8).copy()
     raw = np.zeros(data.nbytes + 64, dtype=np.uint8)

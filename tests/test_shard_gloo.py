@@ -23,7 +23,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,kind,nbytes", [(2, "text", 230000), (2, "runs", 600000), (4, "runs", 900000),
-                                               (4, "text", 480000)])
+                                               (4, "text", 480000), (2, "dups", 420000)])
 def test_round_robin_sharding(oracle, world, kind, nbytes):
     srcs = [os.path.join(ROOT, "bzip2-rust_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "bzip2-rust_amd", "csrc"))]
     if not os.path.exists(EMU_PATH) or any(os.path.getmtime(s) > os.path.getmtime(EMU_PATH) for s in srcs):
