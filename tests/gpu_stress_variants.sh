@@ -21,8 +21,8 @@ rm -f $LOG
 for v in sA sB sC sD sE; do
   export BZX_LIB=bzip2-rust_amd/libbzx_$v.so
   echo "== $v" >> $LOG
-  timeout -k 10 150 python tests/gpu_probe_fuzz.py 31 1200 2>&1 | tail -n 1 >> $LOG
-  timeout -k 10 150 python tests/gpu_probe_fuzz_big.py 32 200 2>&1 | tail -n 1 >> $LOG
+  timeout -k 10 150 python tests/gpu_probe_fuzz.py ${SEED:-31} ${NSMALL:-1200} 2>&1 | tail -n 1 >> $LOG
+  timeout -k 10 150 python tests/gpu_probe_fuzz_big.py $((${SEED:-31}+1)) ${NBIG:-200} 2>&1 | tail -n 1 >> $LOG
   for c in hdr py; do timeout -k 10 200 python tests/gpu_probe_pieces.py $c 128 2>&1 | tail -n 1 >> $LOG; done
   timeout -k 10 150 python tests/gpu_probe_bsort.py 128 so,zeros,text 2>&1 | grep -o "^[a-z-]* \|blocks-left [0-9]* from-scratch [0-9]*\|parity=[A-Z]*" | tr "\n" " " >> $LOG
   echo >> $LOG
