@@ -59,6 +59,9 @@
 #ifndef BS_KEYBITS
 #define BS_KEYBITS 32                   // leading bits of the 32-bit record key sorted by the initial LSD passes (a multiple of 8)
 #endif
+#ifndef BS_OPTIMISTIC
+#define BS_OPTIMISTIC 1                 // initial sort by returning LDS atomics, checked (0: ballot-ranked passes only)
+#endif
 #define BS_TINY 64                      // groups up to this size are ranked by counting
 #define BS_MED 512                      // ... up to this size by one wave
 #define REC_IDX(r) ((uint32_t)((r) >> 12) & 0xFFFFFu)
@@ -628,6 +631,100 @@ __device__ __attribute__((noinline)) void wg_radix_sort(uint32_t base, uint32_t 
     }
 }
 
+// Optimistic form of the pass above for the initial sort of s_x[0 .. cnt): a record's stable rank among the records of
+// its wave with the same digit is the value ONE returning LDS atomic hands back -- no ballots.  That is the stable
+// rank only if the LDS serves the lanes of a wave instruction that hit the same counter in lane order, which gfx950
+// does in every trial (tools/ubench/lds_order.hip: 4.2e9 lane operations under load, none out of order) but which no
+// manual promises.  So the caller does not trust it: it checks that the keys come out in non-decreasing order -- a
+// pass that broke stability where it matters leaves an inversion of the full key, and an order that differs only among
+// records with equal keys is as good as any other, since a tied group is refined as a set -- and sorts the bucket
+// again with the ballot-ranked passes if they do not.  Random-address LDS atomics run at the rate of random LDS reads
+// (~7 cycles per wave instruction), so a pass costs about three random LDS operations per row instead of five plus
+// ~45 vector instructions of ballot ranking.
+__device__ __attribute__((noinline)) void wg_radix_sort_opt(uint32_t cnt, int lo, int hi)
+{
+    uint64_t *A = s_x;
+    const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
+    const uint32_t rows = (cnt + SK_NT - 1) / SK_NT, chunk = rows * 64;
+    if (tid == 0) {
+        s_bc[5] = 0;
+        s_bc[6] = 0;
+    }
+    __syncthreads();
+    {
+        const uint64_t a0 = A[0];
+        uint64_t d = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t e = wave * chunk + j * 64 + lane;
+            if (j < rows && e < cnt) d |= A[e] ^ a0;
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) d |= __shfl_xor(d, s);
+        if (lane == 0 && d) {
+            atomicOr(&s_bc[5], (uint32_t)d);
+            atomicOr(&s_bc[6], (uint32_t)(d >> 32));
+        }
+    }
+    __syncthreads();
+    const uint64_t diff = ((uint64_t)s_bc[6] << 32) | s_bc[5];
+    uint32_t *wc = s_cnt[wave];
+    for (int shift = lo; shift < hi; shift += SK_DB) {
+        if (((diff >> shift) & (uint64_t)(SK_ND - 1)) == 0) continue;
+#pragma unroll
+        for (uint32_t i = 0; i < SK_ND / 64; i++) wc[i * 64 + lane] = 0;
+        lds_order();
+        uint64_t v[BS_E];
+        uint32_t old[BS_E];
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t e = wave * chunk + j * 64 + lane;
+            v[j] = j < rows && e < cnt ? A[e] : 0ull;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t e = wave * chunk + j * 64 + lane;
+            old[j] = 0;
+            if (j < rows && e < cnt) old[j] = atomicAdd(&wc[(uint32_t)(v[j] >> shift) & (SK_ND - 1)], 1u);
+            lds_order();                                    // rows in order: a wave's LDS instructions execute in issue order
+        }
+        __syncthreads();
+        {
+            // exclusive start of every (digit, wave): one digit per thread, over waves first, then over digits; the
+            // digit's start is folded into the per-wave counters
+            static_assert(SK_ND <= SK_NT, "one digit per thread");
+            if (tid < SK_ND) {
+                uint32_t t[SK_NW], sum = 0;
+#pragma unroll
+                for (int w = 0; w < SK_NW; w++) {
+                    t[w] = s_cnt[w][tid];
+                    sum += t[w];
+                }
+                const uint32_t incl = bzx_wave_incl_sum(sum);
+                uint32_t run = incl - sum;
+#pragma unroll
+                for (int w = 0; w < SK_NW; w++) {
+                    s_cnt[w][tid] = run;
+                    run += t[w];
+                }
+                if (lane == 63) s_part[wave] = incl;
+            }
+        }
+        __syncthreads();
+        const uint32_t p1 = s_part[0], p2 = p1 + s_part[1], p3 = p2 + s_part[2];
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t e = wave * chunk + j * 64 + lane;
+            if (j < rows && e < cnt) {
+                const uint32_t d = (uint32_t)(v[j] >> shift) & (SK_ND - 1);
+                const uint32_t q = d >> 6;                   // wave of the thread that scanned digit d
+                A[wc[d] + (q == 0 ? 0u : q == 1 ? p1 : q == 2 ? p2 : p3) + old[j]] = v[j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // The same for s_w[base .. base+s), s <= BS_MED, by ONE wave (all 64 lanes call it together; no workgroup barriers).
 __device__ __attribute__((noinline)) void wave_radix_sort(uint32_t base, uint32_t s, int lo, int hi)
 {
@@ -735,6 +832,34 @@ __device__ __forceinline__ bool any_big(uint32_t base, uint32_t s, uint32_t t, u
     return big;
 }
 
+// Initial sort of the bucket's records s_x[0 .. cnt) by their 32 key bits; afterwards rank p holds record p
+// (s_w[p] = p) and the group-start flags say where the key differs from the predecessor's.  The optimistic passes
+// run first (see wg_radix_sort_opt); an inversion among the sorted keys -- never seen -- sends the bucket through the
+// ballot-ranked passes, whose order needs no checking.  *resorted counts such buckets.
+__device__ __attribute__((noinline)) void initial_sort(uint32_t cnt, uint32_t *resorted)
+{
+    for (int attempt = 0;; attempt++) {
+        if (attempt == 0 && BS_OPTIMISTIC) wg_radix_sort_opt(cnt, 64 - BS_KEYBITS, 64);
+        else wg_radix_sort<0>(0, cnt, 64 - BS_KEYBITS, 64);
+        const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+        int bad = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t p = j * SK_NT + tid;
+            s_w[p] = p;
+            const uint64_t kp = s_x[p] >> (64 - BS_KEYBITS), kq = p ? s_x[p - 1] >> (64 - BS_KEYBITS) : 0ull;
+            const bool f = p >= cnt || p == 0 || kp != kq;
+            bad |= p < cnt && p > 0 && kp < kq;
+            const uint64_t m = __ballot(f);
+            if (lane == 0) s_f[j * SK_NW + wave] = m;
+        }
+        if (tid == 0) s_f[BS_FW] = ~0ull;
+        bad = __syncthreads_or(bad);
+        if (!bad || attempt) break;
+        if (tid == 0) atomicAdd(resorted, 1u);
+    }
+}
+
 // Rank array (rank of every rotation, uint32[BZX_MAX_N]) of the k-th block of resume_list: the sort slots of the
 // general sorter hold eight such arrays each and are idle while the rank rounds run.  nullptr: none left.
 __device__ __forceinline__ uint32_t *rank_array(const BzxBatch &B, uint32_t k)
@@ -807,19 +932,7 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
         }
         if (tid == 0) s_rc[0][0] = s_rc[0][1] = s_rc[0][2] = s_rc[0][3] = 0;
         DIAG_STAMP(65);
-        wg_radix_sort<0>(0, cnt, 64 - BS_KEYBITS, 64);          // (its first barrier also publishes s_x)
-        DIAG_STAMP(66);
-        // rank p holds record p; group starts: the 32 key bits differ from the predecessor's
-#pragma unroll
-        for (uint32_t j = 0; j < BS_E; j++) {
-            const uint32_t p = j * SK_NT + tid;
-            s_w[p] = p;
-            const bool f = p >= cnt || p == 0 || (s_x[p] >> (64 - BS_KEYBITS)) != (s_x[p - 1] >> (64 - BS_KEYBITS));
-            const uint64_t m = __ballot(f);
-            if (lane == 0) s_f[j * SK_NW + wave] = m;
-        }
-        if (tid == 0) s_f[BS_FW] = ~0ull;
-        __syncthreads();
+        initial_sort(cnt, &B.counters[BZX_CTR_STAT0 + 15]);     // (its first barrier also publishes s_x)
         DIAG_STAMP(67);
 
         uint32_t dcur = depth0 + BS_KEYBITS;
