@@ -471,37 +471,14 @@ __shared__ uint32_t s_med[BS_C / BS_TINY + 1];     // groups of 65..512: first r
 __shared__ uint32_t s_large[BS_C / BS_MED + 1];    // larger groups
 __shared__ uint32_t s_rc[2][4];              // per round (parity): [0] any rank tied, [1] #med, [2] #large, [3] med fetch
 __shared__ uint32_t s_bc[8];                 // [2] vote, [5..6] diff
+__shared__ uint32_t s_m[2];                  // lengths of the two lists of tied ranks
+__shared__ uint32_t s_red[SK_NW][4];         // per wave: OR (lo, hi) and AND (lo, hi) of the bucket's records as loaded
 
 template <int WHICH> __device__ __forceinline__ uint64_t *lds_arr() { return WHICH ? s_w : s_x; }
 
-// Ordering point between LDS operations of ONE wave: the hardware executes a wave's LDS instructions in issue order
-// and all its lanes together, so only the compiler has to keep them in program order (no s_waitcnt is needed: a
-// fence would drain the LDS queue and a volatile access through a generic pointer becomes a FLAT load with a full
-// wait).  The CPU emulator runs lanes one after the other and needs a real rendezvous.
-#ifdef BZX_HIP_EMU
-#define lds_order() hipemu::wave_sync()
-#else
-#define lds_order() asm volatile("" ::: "memory")
-#endif
-
-// A value every lane of the workgroup loaded from the same address: keep it in a scalar register (values that are
-// live across the calls below would otherwise be spilled around every call: only 24 of 80 VGPRs are callee-saved).
-#ifdef BZX_HIP_EMU
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return v; }
-#else
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-#endif
-// The lane id, opaque to the optimiser: re-read at the top of a loop body it keeps address arithmetic derived from
-// it from being hoisted out of the loop, where dozens of such values would be spilled and reloaded from scratch
-// (global memory) inside the hot loops.
-__device__ __forceinline__ uint32_t tid_here()
-{
-    uint32_t t = threadIdx.x;
-#ifndef BZX_HIP_EMU
-    asm volatile("" : "+v"(t));
-#endif
-    return t;
-}
+// (lds_order, bzx_uni, bzx_tid_here: bzx_wg.h)
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return bzx_uni(v); }
+__device__ __forceinline__ uint32_t tid_here() { return bzx_tid_here(); }
 __device__ __forceinline__ BzxBucket uni(BzxBucket b)
 {
     BzxBucket r;
@@ -646,28 +623,19 @@ __device__ __attribute__((noinline)) void wg_radix_sort_opt(uint32_t cnt, int lo
     uint64_t *A = s_x;
     const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
     const uint32_t rows = (cnt + SK_NT - 1) / SK_NT, chunk = rows * 64;
-    if (tid == 0) {
-        s_bc[5] = 0;
-        s_bc[6] = 0;
-    }
-    __syncthreads();
+    __syncthreads();                            // publishes s_x and the waves' OR / AND of their records (s_red)
+    uint64_t diff;
     {
-        const uint64_t a0 = A[0];
-        uint64_t d = 0;
+        uint32_t o0 = 0, o1 = 0, a0 = ~0u, a1 = ~0u;
 #pragma unroll
-        for (uint32_t j = 0; j < BS_E; j++) {
-            const uint32_t e = wave * chunk + j * 64 + lane;
-            if (j < rows && e < cnt) d |= A[e] ^ a0;
+        for (int w = 0; w < SK_NW; w++) {
+            o0 |= s_red[w][0];
+            o1 |= s_red[w][1];
+            a0 &= s_red[w][2];
+            a1 &= s_red[w][3];
         }
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) d |= __shfl_xor(d, s);
-        if (lane == 0 && d) {
-            atomicOr(&s_bc[5], (uint32_t)d);
-            atomicOr(&s_bc[6], (uint32_t)(d >> 32));
-        }
+        diff = ((uint64_t)(o1 & ~a1) << 32) | (o0 & ~a0);        // bits on which the records differ
     }
-    __syncthreads();
-    const uint64_t diff = ((uint64_t)s_bc[6] << 32) | s_bc[5];
     uint32_t *wc = s_cnt[wave];
     for (int shift = lo; shift < hi; shift += SK_DB) {
         if (((diff >> shift) & (uint64_t)(SK_ND - 1)) == 0) continue;
@@ -832,6 +800,40 @@ __device__ __forceinline__ bool any_big(uint32_t base, uint32_t s, uint32_t t, u
     return big;
 }
 
+// The list of tied ranks lives in the key halves of s_x, which are dead once the initial sort has set the group-start
+// flags: two lists of 16-bit ranks (one read, one written), entry i in the upper dword of s_x[i].
+#define LIST(which, i) (reinterpret_cast<uint16_t *>(s_x)[4u * (i) + 2u + (which)])
+
+// Ranks that are tied (not alone in their group) -> list `to`, whose length s_m[to] must be zero: all ranks of the
+// bucket (ALL, n = its size), or the entries of list `from` (n = its length).  One LDS atomic per wave and row of 64
+// candidates reserves the entries; the list is a concatenation of ascending pieces in no particular order -- every
+// step of a round works on the ranks, not on their order in the list.
+template <bool ALL>
+__device__ __attribute__((noinline)) void list_tied(uint32_t n, uint32_t from, uint32_t to)
+{
+    const uint32_t tid = tid_here(), lane = tid & 63u;
+    const uint32_t nrow = (n + SK_NT - 1) / SK_NT;
+#pragma unroll
+    for (uint32_t j = 0; j < BS_E; j++) {
+        if (j < nrow) {
+            const uint32_t i = j * SK_NT + tid;
+            uint32_t p = 0;
+            bool t = false;
+            if (i < n) {
+                p = ALL ? i : (uint32_t)LIST(from, i);
+                t = !(fbit(p) && fbit(p + 1));
+            }
+            const uint64_t mk = __ballot(t);
+            if (mk) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_m[to], (uint32_t)__popcll(mk));
+                base = bzx_bcast0(base);
+                if (t) LIST(to, base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))) = (uint16_t)p;
+            }
+        }
+    }
+}
+
 // Initial sort of the bucket's records s_x[0 .. cnt) by their 32 key bits; afterwards rank p holds record p
 // (s_w[p] = p) and the group-start flags say where the key differs from the predecessor's.  The optimistic passes
 // run first (see wg_radix_sort_opt); an inversion among the sorted keys -- never seen -- sends the bucket through the
@@ -911,99 +913,137 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
         const bool skip = cnt == 0 || (cnt >> 31) || (st_cur & BZX_ST_REDO) || (B.bsort_mode == 1 && !(st_cur & BZX_ST_RESUME));
         DIAG_STAMP(64);
         if (!skip) {
+            // (the bits on which the records differ, for the radix passes to skip digits all agree on: OR and AND of the
+            // records of every wave, combined by the readers after the first barrier of the sort)
+            uint32_t o0 = 0, o1 = 0, a0 = ~0u, a1 = ~0u;
 #pragma unroll
-            for (uint32_t j = 0; j < BS_E; j++) s_x[j * SK_NT + tid] = nxt[j];
+            for (uint32_t j = 0; j < BS_E; j++) {
+                s_x[j * SK_NT + tid] = nxt[j];
+                if (j * SK_NT + tid < cnt) {
+                    o0 |= (uint32_t)nxt[j];
+                    o1 |= (uint32_t)(nxt[j] >> 32);
+                    a0 &= (uint32_t)nxt[j];
+                    a1 &= (uint32_t)(nxt[j] >> 32);
+                }
+            }
+            o0 = bzx_wave_incl_or(o0);
+            o1 = bzx_wave_incl_or(o1);
+            a0 = bzx_wave_incl_and(a0);
+            a1 = bzx_wave_incl_and(a1);
+            if (lane == 63) {
+                s_red[wave][0] = o0;
+                s_red[wave][1] = o1;
+                s_red[wave][2] = a0;
+                s_red[wave][3] = a1;
+            }
         }
+        // The next bucket's records travel in registers while this one is finished: the loads are issued after the
+        // refinement rounds (whose register needs leave no room for them: issued at the top of the iteration they were
+        // spilled to scratch and reloaded), and land during the write-out and the next bucket's first barrier.
         uint32_t n_nx = 0, st_nx = 0;
-        if (nit.cnt) {
-            const uint64_t *__restrict__ src = ((nit.start >> 31) ? B.rec_b : B.rec_a) + BZX_SLAB(B, nit.blk) * BZX_MAX_N +
-                                               (nit.start & 0x7fffffffu);
-#pragma unroll
-            for (uint32_t j = 0; j < BS_E; j++) nxt[j] = j * SK_NT + tid < nit.cnt ? src[j * SK_NT + tid] : ~0ull;
-            n_nx = B.blk[nit.blk].n;                                   // (made scalar when it becomes n_cur)
-            st_nx = __atomic_load_n(&B.blk[nit.blk].status, __ATOMIC_RELAXED);
+#define PREFETCH_NEXT()                                                                                                   \
+        if (nit.cnt) {                                                                                                    \
+            const uint64_t *__restrict__ src = ((nit.start >> 31) ? B.rec_b : B.rec_a) + BZX_SLAB(B, nit.blk) * BZX_MAX_N + \
+                                               (nit.start & 0x7fffffffu);                                                 \
+            const uint32_t tp_ = tid_here();                                                                              \
+            _Pragma("unroll") for (uint32_t j = 0; j < BS_E; j++) nxt[j] = j * SK_NT + tp_ < nit.cnt ? src[j * SK_NT + tp_] : ~0ull; \
+            n_nx = B.blk[nit.blk].n;                                   /* (made scalar when it becomes n_cur) */          \
+            st_nx = __atomic_load_n(&B.blk[nit.blk].status, __ATOMIC_RELAXED);                                            \
         }
         if (skip) {
+            PREFETCH_NEXT();
             it = nit;
             nit = uni(nit2);
             n_cur = uni(n_nx);
             st_cur = uni(st_nx);
             continue;
         }
-        if (tid == 0) s_rc[0][0] = s_rc[0][1] = s_rc[0][2] = s_rc[0][3] = 0;
+        if (tid == 0) s_rc[0][0] = s_rc[0][1] = s_rc[0][2] = s_rc[0][3] = s_m[0] = s_m[1] = 0;
         DIAG_STAMP(65);
         initial_sort(cnt, &B.counters[BZX_CTR_STAT0 + 15]);     // (its first barrier also publishes s_x)
         DIAG_STAMP(67);
 
+        // ---- refinement rounds over the LIST of tied ranks.  After 47 key bits most ranks are alone in their group (83 %
+        // on text), so the rounds do not walk the bucket: the tied ranks are compacted into a list and every step of a
+        // round -- gather, group tiers, write-back -- runs over list entries only, with all lanes busy; the list is
+        // filtered again after every round, and an empty list ends the bucket without a checking round.
         uint32_t dcur = depth0 + BS_KEYBITS;
         bool fail = false;
+        uint32_t lpar = 0;
+        list_tied<true>(cnt, 0, 0);
+        __syncthreads();
+        DIAG_STAMP(73);
         for (uint32_t round = 0;; round++) {
             tid = tid_here();
             lane = tid & 63u;
             wave = tid >> 6;
             const uint32_t par = round & 1u;
-            const bool can = round < BS_ROUNDS && dcur < nbits;
-            // tied ranks fetch their next 50 key bits (bit offsets wrap at the block end): all gathers of a lane
-            // are issued together; groups above BS_TINY are listed while they are in flight
-            uint32_t tmask = 0, hmask = 0;                          // bit j: rank of row j is tied / heads its group
-            uint32_t xa[BS_E], pos[BS_E];
-#pragma unroll
-            for (uint32_t j = 0; j < BS_E; j++) {
-                const uint32_t p = j * SK_NT + tid;
-                const uint32_t f0 = p < cnt ? fbit(p) : 1u, f1 = p < cnt ? fbit(p + 1) : 1u;
-                xa[j] = 0;
-                pos[j] = 0;
-                if (!(f0 && f1)) {
-                    tmask |= 1u << j;
-                    hmask |= f0 << j;
-                    pos[j] = (uint32_t)(s_w[p] & W_POS_MASK);
-                }
-            }
-            uint64_t g[BS_E];
-            if (can) {
-#pragma unroll
-                for (uint32_t j = 0; j < BS_E; j++) {
-                    if ((tmask >> j) & 1u) {
-                        uint32_t x = REC_IDX(s_x[pos[j]]) * bits + dcur;
-                        if (x >= nbits) x -= nbits;
-                        xa[j] = x;
-                    }
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < BS_E; j++) g[j] = ((tmask >> j) & 1u) ? pk_window_bit(P, xa[j]) : 0ull;
-#pragma unroll
-                for (uint32_t j = 0; j < BS_E; j++) {
-                    if ((hmask >> j) & 1u) {                                    // first rank of its group: measure it
-                        const uint32_t p = j * SK_NT + tid;
-                        uint32_t wi = p >> 6;
-                        uint64_t w = (s_f[wi] >> (p & 63u)) >> 1;               // flags after p
-                        uint32_t e;
-                        if (w) {
-                            e = p + 1u + (uint32_t)__builtin_ctzll(w);
-                        } else {
-                            do w = s_f[++wi]; while (!w);                       // ends at the sentinel word at the latest
-                            e = wi * 64 + (uint32_t)__builtin_ctzll(w);
-                        }
-                        const uint32_t size = e - p;
-                        if (size > BS_MED) s_large[atomicAdd(&s_rc[par][2], 1u)] = p | (size << 16);
-                        else if (size > BS_TINY) s_med[atomicAdd(&s_rc[par][1], 1u)] = p | (size << 16);
-                    }
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < BS_E; j++)
-                    if ((tmask >> j) & 1u) s_w[j * SK_NT + tid] = (g[j] & ~W_POS_MASK) | (uint64_t)pos[j];
-            }
-            if (tmask) s_rc[par][0] = 1;
-            if (tid == 0) s_rc[par ^ 1u][0] = s_rc[par ^ 1u][1] = s_rc[par ^ 1u][2] = s_rc[par ^ 1u][3] = 0;
-            __syncthreads();
-            DIAG_STAMP(68);
-            if (s_rc[par][0] == 0) break;
-            if (!can) {                                            // deep repeats / identical rotations: rank rounds
+            const uint32_t m = uni(s_m[lpar]);                       // tied ranks
+            if (m == 0) break;
+            if (!(round < BS_ROUNDS && dcur < nbits)) {                // deep repeats / identical rotations: rank rounds
                 DIAG_COUNT(round >= BS_ROUNDS ? 84 : 85, 1);
                 fail = true;
                 break;
             }
             DIAG_COUNT(80, 1);
+            DIAG_COUNT(88, m);
+            const uint32_t nrow = (m + SK_NT - 1) / SK_NT;
+            // tied ranks fetch their next 50 key bits (bit offsets wrap at the block end): all gathers of a lane
+            // are issued together; groups above BS_TINY are listed while they are in flight
+            uint32_t amask = 0, hmask = 0;                          // bit j: entry j of this lane exists / heads its group
+            uint32_t pq[BS_E], xa[BS_E];                            // rank | position of its record in s_x << 16
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) {
+                pq[j] = 0;
+                xa[j] = 0;
+                if (j < nrow) {
+                    const uint32_t i = j * SK_NT + tid;
+                    if (i < m) {
+                        const uint32_t p = LIST(lpar, i);
+                        amask |= 1u << j;
+                        hmask |= fbit(p) << j;
+                        pq[j] = p | ((uint32_t)(s_w[p] & W_POS_MASK) << 16);
+                    }
+                }
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) {
+                if ((amask >> j) & 1u) {
+                    uint32_t x = REC_IDX(s_x[pq[j] >> 16]) * bits + dcur;
+                    if (x >= nbits) x -= nbits;
+                    xa[j] = x;
+                }
+            }
+            uint64_t g[BS_E];
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) g[j] = ((amask >> j) & 1u) ? pk_window_bit(P, xa[j]) : 0ull;
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) {
+                if ((hmask >> j) & 1u) {                                    // first rank of its group: measure it
+                    const uint32_t p = pq[j] & 0xFFFFu;
+                    uint32_t wi = p >> 6;
+                    uint64_t w = (s_f[wi] >> (p & 63u)) >> 1;               // flags after p
+                    uint32_t e;
+                    if (w) {
+                        e = p + 1u + (uint32_t)__builtin_ctzll(w);
+                    } else {
+                        do w = s_f[++wi]; while (!w);                       // ends at the sentinel word at the latest
+                        e = wi * 64 + (uint32_t)__builtin_ctzll(w);
+                    }
+                    const uint32_t size = e - p;
+                    if (size > BS_MED) s_large[atomicAdd(&s_rc[par][2], 1u)] = p | (size << 16);
+                    else if (size > BS_TINY) s_med[atomicAdd(&s_rc[par][1], 1u)] = p | (size << 16);
+                }
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++)
+                if ((amask >> j) & 1u) s_w[pq[j] & 0xFFFFu] = (g[j] & ~W_POS_MASK) | (uint64_t)(pq[j] >> 16);
+            if (tid == 0) {
+                s_rc[par ^ 1u][0] = s_rc[par ^ 1u][1] = s_rc[par ^ 1u][2] = s_rc[par ^ 1u][3] = 0;
+                s_m[lpar ^ 1u] = 0;
+            }
+            __syncthreads();
+            DIAG_STAMP(68);
             const uint32_t nmed = s_rc[par][1], nlarge = s_rc[par][2];
             if (nmed | nlarge) {
                 DIAG_COUNT(86, nmed);
@@ -1043,9 +1083,9 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
             tid = tid_here();
             lane = tid & 63u;
             wave = tid >> 6;
-            // groups of up to BS_TINY ranks: every lane ranks its own word among its group's.  One row at a time, four
-            // members per step (four LDS reads in flight): a row costs as many steps as ITS largest group needs, and
-            // most rows hold only groups of a few ranks.
+            // groups of up to BS_TINY ranks: every lane ranks the word at its list entry among its group's.  One entry
+            // at a time, four members per step (four LDS reads in flight): an entry costs as many steps as the largest
+            // group among the wave's 64 entries needs, and most hold only groups of a few ranks.
             uint32_t dst_[BS_E];                                  // new rank | first-of-sub-group flag << 31; ~0: untouched
             uint64_t my[BS_E];
 #pragma unroll
@@ -1053,27 +1093,29 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
                 dst_[j] = 0xFFFFFFFFu;
                 my[j] = 0;
                 uint32_t a_ = 0, sz = 0;
-                if ((tmask >> j) & 1u) {
-                    const uint32_t p = j * SK_NT + tid;
+                if ((amask >> j) & 1u) {
+                    const uint32_t p = pq[j] & 0xFFFFu;
                     uint32_t e_;
                     if (tiny_bounds(p, a_, e_) && e_ - a_ > 1) {
                         sz = e_ - a_;
                         my[j] = s_w[p];
                     }
                 }
-                uint32_t r = 0, eq = 0;
-                for (uint32_t i = 0; i < sz; i += 4) {
-                    uint64_t wq[4];
+                if (j < nrow) {
+                    uint32_t r = 0, eq = 0;
+                    for (uint32_t i = 0; i < sz; i += 4) {
+                        uint64_t wq[4];
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; k++) wq[k] = s_w[a_ + (i + k < sz ? i + k : sz - 1)];
+                        for (uint32_t k = 0; k < 4; k++) wq[k] = s_w[a_ + (i + k < sz ? i + k : sz - 1)];
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; k++) {
-                        const bool lt = i + k < sz && wq[k] < my[j];
-                        r += lt;
-                        eq += lt && ((wq[k] ^ my[j]) >> 14) == 0;
+                        for (uint32_t k = 0; k < 4; k++) {
+                            const bool lt = i + k < sz && wq[k] < my[j];
+                            r += lt;
+                            eq += lt && ((wq[k] ^ my[j]) >> 14) == 0;
+                        }
                     }
+                    if (sz) dst_[j] = (a_ + r) | (eq ? 0u : 0x80000000u);
                 }
-                if (sz) dst_[j] = (a_ + r) | (eq ? 0u : 0x80000000u);
             }
             __syncthreads();
             DIAG_STAMP(70);
@@ -1087,8 +1129,13 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
             }
             __syncthreads();
             DIAG_STAMP(71);
+            list_tied<false>(m, lpar, lpar ^ 1u);                  // the ranks of the list that are still tied
+            __syncthreads();
+            DIAG_STAMP(73);
+            lpar ^= 1u;
             dcur += 50;
         }
+        PREFETCH_NEXT();
         tid = tid_here();
         if (fail || B.bsort_mode == 1) {
             // A bucket that gave up keeps what it has: the order so far and the group starts go to the (dead) record

@@ -824,9 +824,7 @@ __device__ __attribute__((noinline)) void big_split_pass(uint64_t *__restrict__ 
             Utmp[ks + pos] = ((uint64_t)(g0 + hist[dg]) << G_SHIFT) | (rec & LOW) | ((!TEXT && hist[dg]) ? RNK_MOVED : 0ull);
         }
         // all lanes' stores must have landed before the wave reads the range back
-#ifndef BZX_HIP_EMU
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+        bzx_drain_stores();
         bzx_wave_sync();
         for (uint32_t o = lane; o < size; o += 64) U[ks + o] = Utmp[ks + o];
         bzx_wave_sync();

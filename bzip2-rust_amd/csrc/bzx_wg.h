@@ -26,6 +26,38 @@
     } while (0)
 #endif
 
+
+// ---- the remaining device / emulator differences (the product sources have no other BZX_HIP_EMU sites) ----------
+// lds_order(): ordering point between LDS operations of ONE wave.  The hardware executes a wave's LDS instructions in
+// issue order and all its lanes together, so only the compiler has to keep them in program order (no s_waitcnt is
+// needed: a fence would drain the LDS queue, and a volatile access through a generic pointer becomes a FLAT load with
+// a full wait).  The CPU emulator runs lanes one after the other and needs a real rendezvous.
+// bzx_uni(): a value every lane of the workgroup loaded from the same address, kept in a scalar register (values live
+// across calls would otherwise be spilled around every call: only 24 of 80 VGPRs are callee-saved).
+// bzx_bcast0(): lane 0's value to the whole wave (all lanes active).
+// bzx_tid_here(): the lane id, opaque to the optimiser: re-read at the top of a loop body it keeps address arithmetic
+// derived from it from being hoisted out of the loop, where dozens of such values would be spilled and reloaded from
+// scratch (global memory) inside the hot loops.
+// bzx_drain_stores(): all of this lane's global stores have landed (before the wave reads them back).
+#ifdef BZX_HIP_EMU
+#define lds_order() hipemu::wave_sync()
+__device__ __forceinline__ uint32_t bzx_uni(uint32_t v) { return v; }
+__device__ __forceinline__ uint32_t bzx_bcast0(uint32_t v) { return __shfl(v, 0); }
+__device__ __forceinline__ uint32_t bzx_tid_here() { return threadIdx.x; }
+#define bzx_drain_stores() do {} while (0)
+#else
+#define lds_order() asm volatile("" ::: "memory")
+__device__ __forceinline__ uint32_t bzx_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t bzx_bcast0(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t bzx_tid_here()
+{
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+#define bzx_drain_stores() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 __device__ __forceinline__ uint32_t bzx_lane() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t bzx_wave() { return threadIdx.x >> 6; }
 
@@ -41,25 +73,63 @@ __device__ __forceinline__ uint64_t bzx_match_any(uint32_t d, int nbits, bool va
     return peers;
 }
 
+// Wave inclusive scans and reductions.  On the device they are six DPP steps (row_shr 1,2,4,8 inside the rows of 16
+// lanes, then row_bcast 15 / 31 across rows): plain vector instructions, no trip through the LDS crossbar as a
+// __shfl_up (ds_bpermute_b32 + wait) per step would be -- these scans sit between two workgroup barriers of every
+// radix pass, so their latency is everybody's.  The CPU emulator has no DPP and keeps the shuffle form.
+#ifdef BZX_HIP_EMU
+#define BZX_DPP_SCAN(v, OP, IDENT)                                           \
+    do {                                                                     \
+        const uint32_t lane_ = bzx_lane();                                   \
+        for (uint32_t d_ = 1; d_ < 64; d_ <<= 1) {                           \
+            const uint32_t y_ = __shfl_up(v, d_);                            \
+            if (lane_ >= d_) v = OP(v, y_);                                  \
+        }                                                                    \
+    } while (0)
+#else
+#define BZX_DPP_STEP(v, OP, IDENT, CTRL, ROWMASK)                                                                 \
+    do {                                                                                                         \
+        const uint32_t y_ = (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)(v), CTRL, ROWMASK, 0xf, false); \
+        v = OP(v, y_);                                                                                           \
+    } while (0)
+#define BZX_DPP_SCAN(v, OP, IDENT)                                           \
+    do {                                                                     \
+        BZX_DPP_STEP(v, OP, IDENT, 0x111, 0xf);      /* row_shr:1 */         \
+        BZX_DPP_STEP(v, OP, IDENT, 0x112, 0xf);      /* row_shr:2 */         \
+        BZX_DPP_STEP(v, OP, IDENT, 0x114, 0xf);      /* row_shr:4 */         \
+        BZX_DPP_STEP(v, OP, IDENT, 0x118, 0xf);      /* row_shr:8 */         \
+        BZX_DPP_STEP(v, OP, IDENT, 0x142, 0xa);      /* row_bcast:15 */      \
+        BZX_DPP_STEP(v, OP, IDENT, 0x143, 0xc);      /* row_bcast:31 */      \
+    } while (0)
+#endif
+#define BZX_OP_ADD(a, b) ((a) + (b))
+#define BZX_OP_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define BZX_OP_OR(a, b) ((a) | (b))
+#define BZX_OP_AND(a, b) ((a) & (b))
+
 // Wave inclusive sum scan.
 __device__ __forceinline__ uint32_t bzx_wave_incl_sum(uint32_t v)
 {
-    const uint32_t lane = bzx_lane();
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(v, d);
-        if (lane >= d) v += y;
-    }
+    BZX_DPP_SCAN(v, BZX_OP_ADD, 0u);
     return v;
 }
 
 // Wave inclusive max scan.
 __device__ __forceinline__ uint32_t bzx_wave_incl_max(uint32_t v)
 {
-    const uint32_t lane = bzx_lane();
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(v, d);
-        if (lane >= d && y > v) v = y;
-    }
+    BZX_DPP_SCAN(v, BZX_OP_MAX, 0u);
+    return v;
+}
+
+// OR / AND over the wave: the result is valid in lane 63 (inclusive scans).
+__device__ __forceinline__ uint32_t bzx_wave_incl_or(uint32_t v)
+{
+    BZX_DPP_SCAN(v, BZX_OP_OR, 0u);
+    return v;
+}
+__device__ __forceinline__ uint32_t bzx_wave_incl_and(uint32_t v)
+{
+    BZX_DPP_SCAN(v, BZX_OP_AND, 0xFFFFFFFFu);
     return v;
 }
 

@@ -20,10 +20,10 @@ def collect(patterns, limit):
                 return bytes(out[:limit])
     return bytes(out)
 DIAG = "diag" in os.environ.get("BZX_LIB", "")
-SORT_SLOTS = {64: "fetch", 65: "load", 66: "sort32", 67: "flags", 68: "w-build+list", 69: "big-groups", 70: "tiny-rank",
+SORT_SLOTS = {64: "fetch", 65: "load", 66: "sort32", 67: "sort32+flags", 73: "list", 68: "w-build+list", 69: "big-groups", 70: "tiny-rank",
               71: "tiny-write", 72: "output"}
 SPLIT_SLOTS = {96: "fetch", 97: "in-use", 98: "pack", 99: "hist", 100: "form", 101: "partition", 102: "emit", 103: "deeper"}
-COUNTS = {80: "rounds", 83: "buckets-done", 84: "fail-rounds", 85: "fail-depth", 86: "medium-groups", 87: "large-groups",
+COUNTS = {80: "rounds", 88: "tied-entries", 83: "buckets-done", 84: "fail-rounds", 85: "fail-depth", 86: "medium-groups", 87: "large-groups",
           104: "deep-splits", 105: "deep-split-records", 106: "redo-split-nbk", 107: "redo-split-other"}
 if DIAG:
     lib.lib.bzx_dbg_phase_timers.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
