@@ -107,7 +107,7 @@ __shared__ unsigned long long s_diag[128];
 #endif
 
 // ------------------------------------------------------------------------------------------------ split kernel
-__shared__ uint32_t b_tab[BS_TAB_WORDS];     // bin counts, then bucket ids (index padded: b + b/32)
+__shared__ uint32_t b_tab[BS_TAB_WORDS + BS_MAX_BK];     // bin counts, then bucket ids (index padded: b + b/32); level-1 partition: see there
 __shared__ uint32_t b_start[BS_MAX_BK + 1];  // first rank of every bucket (relative to the range being split)
 __shared__ uint32_t b_first[BS_MAX_BK + 1];  // first bin of every bucket
 __shared__ uint32_t b_cur[BS_MAX_BK];        // scatter cursors
@@ -123,7 +123,7 @@ __shared__ uint32_t b_big[BS_MAX_BIG][3];    // oversized bins: {start | buffer 
 // Bins [0, BINS) counted in TAB -> buckets.  A new bucket starts at bin b when b or b-1 is above BS_ISO, or when
 // the bin's first rank lies in another BS_CP-window than its predecessor's: merged buckets stay below BS_C.
 // Returns the number of buckets (0: more than BS_MAX_BK); TAB(b) = bucket of bin b afterwards.
-template <int BINS>
+template <int BINS, bool TAB16 = false>
 __device__ __forceinline__ uint32_t form_buckets(uint32_t total)
 {
     constexpr int PER = BINS / BS_NT;
@@ -162,7 +162,10 @@ __device__ __forceinline__ uint32_t form_buckets(uint32_t total)
                 b_first[id] = bin0 + k;
                 id++;
             }
-            TAB(bin0 + k) = id - 1;
+            // (TAB16: the bucket ids go to a dense 16-bit table over the start of the count table -- every count was read
+            // into registers before the first scan's barrier, so nobody still needs the words this overwrites)
+            if (TAB16) reinterpret_cast<uint16_t *>(b_tab)[bin0 + k] = (uint16_t)(id - 1);
+            else TAB(bin0 + k) = id - 1;
             s += c[k];
         }
     }
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
         }
         __syncthreads();
         DIAG_STAMP(99);
-        uint32_t nbk = form_buckets<(int)BS_NBIN1>(n);
+        uint32_t nbk = form_buckets<(int)BS_NBIN1, true>(n);
         if (nbk) bucket_setup<BS_BIN1>(nbk);
         __syncthreads();
         DIAG_STAMP(100);
@@ -339,47 +342,118 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
             continue;
         }
 
-        // ---- level 1: one record per rotation into its bucket's range
-        for (uint32_t t0 = 0; t0 < n; t0 += BS_NT * 4 * SP_U) {
-            // the loads of SP_U groups of four rotations are issued before the first group is scattered
-            uint64_t hi[SP_U], lo[SP_U];
-            uint32_t pv[SP_U];                                            // bytes i0-1 .. i0+2 of the block
+        // ---- level 1: one record per rotation into its bucket's range, staged through LDS.  A scattered 8-byte store
+        // per rotation is one L2 request per record, and those requests -- not the bytes -- bounded this kernel (2/3
+        // of its time; tools/ubench/scatter.hip: runs of 16 records go 3.4x faster than single ones).  So the block is
+        // cut into tiles of SP_TILE rotations: a returning LDS atomic per rotation gives its place among the tile's
+        // records for the same bucket, a scan turns the tile's bucket counts into offsets, the records are parked in
+        // LDS in bucket order and leave as runs (~12 records per bucket and tile on text), consecutive lanes writing
+        // consecutive records.  The 16-bit bucket table (64 KB) and the parking area (64 KB) share the histogram's LDS.
+        {
+            constexpr uint32_t SP_TILE = 8192, SP_V = SP_TILE / (BS_NT * 4);       // groups of four rotations per lane and tile
+            static_assert(BS_MAX_BK <= BS_NT && BS_TAB_WORDS >= 32768 + BS_MAX_BK, "tile scan: one bucket per lane");
+            uint16_t *tab16 = reinterpret_cast<uint16_t *>(b_tab);                  // bin -> bucket | shared bits of the bucket << 10
+            for (uint32_t i = tid; i < BS_NBIN1 / 2; i += BS_NT) {
+                uint32_t v = reinterpret_cast<uint32_t *>(b_tab)[i];
+                v |= ((uint32_t)b_b0[v & 1023u] << 10) | ((uint32_t)b_b0[(v >> 16) & 1023u] << 26);
+                reinterpret_cast<uint32_t *>(b_tab)[i] = v;
+            }
+            uint64_t *stage = reinterpret_cast<uint64_t *>(b_tab + 16384);         // [SP_TILE]
+            uint32_t *tcnt0 = b_tab + 32768;                                       // [BS_MAX_BK]
+            uint32_t *delta = b_first;                                             // [BS_MAX_BK] (dead since bucket_setup)
+            // tile counts, then offsets: two arrays used by alternate tiles (the one not in use is zeroed during the
+            // other's scan, which saves a barrier per tile)
+            uint32_t *tcnt1 = tcnt0 + BS_MAX_BK;
+            if (tid < nbk) tcnt0[tid] = tcnt1[tid] = 0;
+            uint64_t hi[SP_V], lo[SP_V];
+            uint32_t pv[SP_V];                                                     // bytes i0-1 .. i0+2 of the block
+            auto load_tile = [&](uint32_t t0) {
 #pragma unroll
-            for (uint32_t u = 0; u < SP_U; u++) {
-                const uint32_t i0 = t0 + (u * BS_NT + tid) * 4;
-                hi[u] = lo[u] = 0;
-                pv[u] = 0;
-                if (i0 < n) {
-                    uint64_t w2[2];
-                    __builtin_memcpy(w2, P + ((i0 * bits) >> 3), 16);     // 128-bit window: 64 valid bits for all four
-                    hi[u] = w2[0];
-                    lo[u] = w2[1];
-                    if (i0 >= 1 && i0 + 3 <= n) {
-                        __builtin_memcpy(&pv[u], T + i0 - 1, 4);
-                    } else {
-                        const uint32_t nvalid = n - i0 < 4u ? n - i0 : 4u;
-                        for (uint32_t e = 0; e < nvalid; e++) pv[u] |= (uint32_t)T[i0 + e ? i0 + e - 1 : n - 1] << (8 * e);
+                for (uint32_t u = 0; u < SP_V; u++) {
+                    const uint32_t i0 = t0 + (u * BS_NT + tid) * 4;
+                    hi[u] = lo[u] = 0;
+                    pv[u] = 0;
+                    if (i0 < n) {
+                        uint64_t w2[2];
+                        __builtin_memcpy(w2, P + ((i0 * bits) >> 3), 16);          // 128-bit window: 64 valid bits for all four
+                        hi[u] = w2[0];
+                        lo[u] = w2[1];
+                        if (i0 >= 1 && i0 + 3 <= n) {
+                            __builtin_memcpy(&pv[u], T + i0 - 1, 4);
+                        } else {
+                            const uint32_t nvalid = n - i0 < 4u ? n - i0 : 4u;
+                            for (uint32_t e = 0; e < nvalid; e++) pv[u] |= (uint32_t)T[i0 + e ? i0 + e - 1 : n - 1] << (8 * e);
+                        }
                     }
                 }
-            }
+            };
+            load_tile(0);
+            bzx_lds_barrier();
+            uint32_t tpar = 0;
+            for (uint32_t t0 = 0; t0 < n; t0 += SP_TILE, tpar ^= 1u) {
+                uint32_t *tcnt = tpar ? tcnt1 : tcnt0, *tother = tpar ? tcnt0 : tcnt1;
+                uint32_t kr[SP_V * 4], key[SP_V * 4], pvc[SP_V];           // bucket | place in the tile's run << 16
 #pragma unroll
-            for (uint32_t u = 0; u < SP_U; u++) {
-                const uint32_t i0 = t0 + (u * BS_NT + tid) * 4;
-                if (i0 < n) {
-                    const uint32_t nvalid = n - i0 < 4u ? n - i0 : 4u;
+                for (uint32_t u = 0; u < SP_V; u++) {
+                    const uint32_t i0 = t0 + (u * BS_NT + tid) * 4;
+                    const uint32_t nvalid = i0 < n ? (n - i0 < 4u ? n - i0 : 4u) : 0u;
                     const uint32_t sh0 = (i0 * bits) & 7u;
                     const uint64_t h = __builtin_bswap64(hi[u]), l = __builtin_bswap64(lo[u]);
+                    pvc[u] = pv[u];
 #pragma unroll
                     for (uint32_t e = 0; e < 4; e++) {
+                        kr[u * 4 + e] = 0xFFFFFFFFu;
+                        key[u * 4 + e] = 0;
                         if (e < nvalid) {
                             const uint32_t sh = sh0 + e * bits;               // <= 31
                             const uint64_t w = sh ? (h << sh) | (l >> (64u - sh)) : h;
-                            const uint32_t k = TAB((uint32_t)(w >> (64 - BS_BIN1)));
-                            const uint32_t key = (uint32_t)((w << b_b0[k]) >> 32);
-                            const uint32_t slot = atomicAdd(&b_cur[k], 1u);
-                            rec_a[b_start[k] + slot] = ((uint64_t)key << 32) | ((uint64_t)(i0 + e) << 12) |
-                                                       ((uint64_t)((pv[u] >> (8 * e)) & 255u) << 4);
+                            const uint32_t kb = tab16[(uint32_t)(w >> (64 - BS_BIN1))], k = kb & 1023u;
+                            key[u * 4 + e] = (uint32_t)((w << (kb >> 10)) >> 32);
+                            kr[u * 4 + e] = k | (atomicAdd(&tcnt[k], 1u) << 16);
                         }
+                    }
+                }
+                if (t0 + SP_TILE < n) load_tile(t0 + SP_TILE);             // (in flight across the barriers below)
+                bzx_lds_barrier();
+                {
+                    // exclusive scan of the tile's bucket counts (one bucket per lane; the wave totals go through a
+                    // scratch row of the tile's parity, so one barrier is enough)
+                    const uint32_t c = tid < nbk ? tcnt[tid] : 0u;
+                    const uint32_t incl = bzx_wave_incl_sum(c);
+                    uint32_t *wtot = b_scratch + tpar * BS_NW;
+                    if (bzx_lane() == 63) wtot[bzx_wave()] = incl;
+                    bzx_lds_barrier();
+                    uint32_t pre = 0;
+                    const uint32_t wv = bzx_wave();
+#pragma unroll
+                    for (uint32_t i = 0; i < BS_NW; i++) pre += i < wv ? wtot[i] : 0u;
+                    const uint32_t ex = pre + incl - c;
+                    if (tid < nbk) {
+                        tcnt[tid] = ex;
+                        tother[tid] = 0;
+                        delta[tid] = b_start[tid] + b_cur[tid] - ex;
+                        b_cur[tid] += c;
+                    }
+                }
+                bzx_lds_barrier();
+#pragma unroll
+                for (uint32_t u = 0; u < SP_V; u++)
+#pragma unroll
+                    for (uint32_t e = 0; e < 4; e++)
+                        if (kr[u * 4 + e] != 0xFFFFFFFFu) {
+                            const uint32_t k = kr[u * 4 + e] & 0xFFFFu, rel = (u * BS_NT + tid) * 4 + e;
+                            stage[tcnt[k] + (kr[u * 4 + e] >> 16)] = ((uint64_t)key[u * 4 + e] << 32) | ((uint64_t)k << 21) | ((uint64_t)rel << 8) |
+                                                                     (uint64_t)((pvc[u] >> (8 * e)) & 255u);
+                        }
+                bzx_lds_barrier();
+                const uint32_t tn = n - t0 < SP_TILE ? n - t0 : SP_TILE;
+#pragma unroll
+                for (uint32_t u = 0; u < SP_TILE / BS_NT; u++) {
+                    const uint32_t i = u * BS_NT + tid;
+                    if (i < tn) {
+                        const uint64_t r = stage[i];
+                        const uint32_t k = (uint32_t)(r >> 21) & 1023u, rel = (uint32_t)(r >> 8) & 8191u;
+                        rec_a[delta[k] + i] = (r & 0xFFFFFFFF00000000ull) | ((uint64_t)(t0 + rel) << 12) | ((r & 255ull) << 4);
                     }
                 }
             }
