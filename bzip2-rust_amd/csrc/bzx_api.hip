@@ -411,7 +411,14 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         uint32_t per_cu = bzx_bwt_max_blocks_per_cu();
         int rc = ensure_slots(ctx, ncu * per_cu);
         if (rc) return rc;
-        const size_t items = (size_t)nblk * BZX_BK_PER_BLOCK < B.bk_cap ? (size_t)nblk * BZX_BK_PER_BLOCK : B.bk_cap;
+        // this launch's share of the bucket work lists: eight lists of items / 8 (cap_slabs >= 16, so at least 4096 each);
+        // ALL of it is zeroed, so an item the split kernel reserved but did not write is an empty one
+        const size_t cap_all = (size_t)ctx->cap_slabs * BZX_BK_PER_BLOCK;
+        const size_t items = ((size_t)nblk * BZX_BK_PER_BLOCK < cap_all ? (size_t)nblk * BZX_BK_PER_BLOCK : cap_all) & ~(size_t)7;
+        B.bk_cap = (uint32_t)items;
+        // few blocks: their buckets are dealt over all eight lists, so that every compute unit gets work; many: a list
+        // holds whole blocks (one L2 per block)
+        B.bk_affine = nblk >= 64 ? 1u : 0u;
         HIP_TRY(ctx, hipMemsetAsync(B.bk_list, 0, items * sizeof(BzxBucket), ctx->stream));
         bzx_launch_bsplit(B, nblk < ncu ? nblk : ncu, ctx->stream);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_b1, ctx->stream));
@@ -600,7 +607,8 @@ static void collect_stage_times(bzx_ctx *ctx)
     ctx->stats.n_open_buckets = ctx->stats.n_open_left = ctx->stats.n_resume_left = ctx->stats.n_from_scratch = 0;
     if (ctx->bsort_used) {
         ctx->stats.n_redo = ctx->h_counters[BZX_CTR_REDO] + ctx->h_counters[BZX_CTR_RESUME];
-        ctx->stats.n_buckets = ctx->h_counters[BZX_CTR_BK_ITEMS];
+        ctx->stats.n_buckets = 0;
+        for (int x = 0; x < 8; x++) ctx->stats.n_buckets += ctx->h_counters[BZX_CTR_BK_LIST0 + x];
         (void)hipEventElapsedTime(&ctx->stats.ms_bwt_split, ctx->ev[0], ctx->ev_b1);
         (void)hipEventElapsedTime(&ctx->stats.ms_bwt_sort, ctx->ev_b1, ctx->ev_b2);
         (void)hipEventElapsedTime(&ctx->stats.ms_bwt_general, ctx->ev_b2, ctx->ev[1]);

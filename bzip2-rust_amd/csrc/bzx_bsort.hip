@@ -115,6 +115,7 @@ __shared__ uint8_t b_b0[BS_MAX_BK];          // bits of the bin index that all b
 __shared__ uint32_t b_inuse[256];
 __shared__ uint8_t b_seq[256];
 __shared__ uint32_t b_scratch[2 * BS_NW];
+__shared__ uint32_t b_lbase[8];              // first item of this block's buckets in each of the eight work lists
 __shared__ uint32_t b_bcast[8];              // [0] block, [2] item base, [3] oversized bins pushed so far, [4] ring overflow
 __shared__ uint32_t b_big[BS_MAX_BIG][3];    // oversized bins: {start | buffer << 31, cnt, depth bits}
 
@@ -192,14 +193,22 @@ __device__ __forceinline__ void bucket_setup(uint32_t nbk)
 // Oversized buckets go to the big list instead (always a single bin: all its BINW bits are shared).
 // Returns false when the big list is full.
 template <int BINW>
-__device__ __forceinline__ bool bucket_emit(const BzxBatch &B, uint32_t blk, uint32_t nbk, uint32_t base, uint32_t buf,
+__device__ __forceinline__ bool bucket_emit(const BzxBatch &B, uint32_t blk, uint32_t jj, uint32_t nbk, uint32_t base, uint32_t buf,
                                             uint32_t depth, uint32_t bits, uint32_t done)
 {
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) b_bcast[2] = atomicAdd(&B.counters[BZX_CTR_BK_ITEMS], nbk);
+    // jj: index of the block in the launch.  The nbk items go to list jj % 8 (bk_affine), or item k to list (jj + k) % 8.
+    const uint32_t tid = threadIdx.x, cap8 = B.bk_cap >> 3;
+    if (tid < 8) {
+        const uint32_t mine = B.bk_affine ? (tid == (jj & 7u) ? nbk : 0u) : (nbk + 7u - ((tid - jj) & 7u)) >> 3;
+        uint32_t at = mine ? atomicAdd(&B.counters[BZX_CTR_BK_LIST0 + tid], mine) : 0u;
+        if (at + mine > cap8) {                        // work list full (the lists are zeroed per batch: unwritten items are empty)
+            b_bcast[4] = 1;
+            at = 0;
+        }
+        b_lbase[tid] = tid * cap8 + at;
+    }
     __syncthreads();
-    const uint32_t ibase = b_bcast[2];
-    if (ibase + nbk > B.bk_cap) return false;      // work list full (the list is zeroed per batch: unwritten items are empty)
+    if (b_bcast[4]) return false;
     for (uint32_t k = tid; k < nbk; k += BS_NT) {
         BzxBucket it;
         it.blk = blk;
@@ -217,7 +226,7 @@ __device__ __forceinline__ bool bucket_emit(const BzxBatch &B, uint32_t blk, uin
             }
             it.cnt = 0;                          // the sort kernel skips empty items
         }
-        B.bk_list[ibase + k] = it;
+        B.bk_list[B.bk_affine ? b_lbase[jj & 7u] + k : b_lbase[(jj + k) & 7u] + (k >> 3)] = it;
     }
     __syncthreads();
     return b_bcast[4] == 0;
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
         }
         __syncthreads();
         DIAG_STAMP(101);
-        bool ok = bucket_emit<BS_BIN1>(B, b, nbk, 0, 0, 0, bits, 0);
+        bool ok = bucket_emit<BS_BIN1>(B, b, j_, nbk, 0, 0, 0, bits, 0);
         DIAG_STAMP(102);
 
         // ---- deeper levels: every oversized bin is split by its next BS_BIN2 bits into the other record buffer
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
                 dst[b_start[k] + slot] = ((uint64_t)key << 32) | (r & 0xFFFFFFFFull);
             }
             __syncthreads();
-            ok = bucket_emit<BS_BIN2>(B, b, nbk, base, buf ^ 1u, depth, bits, done);
+            ok = bucket_emit<BS_BIN2>(B, b, j_, nbk, base, buf ^ 1u, depth, bits, done);
             DIAG_COUNT(104, 1);
             DIAG_COUNT(105, cnt);
         }
@@ -914,10 +923,11 @@ __device__ __attribute__((noinline)) void list_tied(uint32_t n, uint32_t from, u
 // ballot-ranked passes, whose order needs no checking.  *resorted counts such buckets.
 __device__ __attribute__((noinline)) void initial_sort(uint32_t cnt, uint32_t *resorted)
 {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint64_t fm[BS_E];                               // group-start flags of my wave's row j (wave-uniform)
     for (int attempt = 0;; attempt++) {
         if (attempt == 0 && BS_OPTIMISTIC) wg_radix_sort_opt(cnt, 64 - BS_KEYBITS, 64);
         else wg_radix_sort<0>(0, cnt, 64 - BS_KEYBITS, 64);
-        const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
         int bad = 0;
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++) {
@@ -926,13 +936,26 @@ __device__ __attribute__((noinline)) void initial_sort(uint32_t cnt, uint32_t *r
             const uint64_t kp = s_x[p] >> (64 - BS_KEYBITS), kq = p ? s_x[p - 1] >> (64 - BS_KEYBITS) : 0ull;
             const bool f = p >= cnt || p == 0 || kp != kq;
             bad |= p < cnt && p > 0 && kp < kq;
-            const uint64_t m = __ballot(f);
-            if (lane == 0) s_f[j * SK_NW + wave] = m;
+            fm[j] = __ballot(f);
+            if (lane == 0) s_f[j * SK_NW + wave] = fm[j];
         }
         if (tid == 0) s_f[BS_FW] = ~0ull;
         bad = __syncthreads_or(bad);
         if (!bad || attempt) break;
         if (tid == 0) atomicAdd(resorted, 1u);
+    }
+    // The list of tied ranks (see list_tied), straight from the flag words: rank p is tied unless a group starts at p
+    // and at p + 1; the flag after a row's last rank is bit 0 of the next flag word (ranks from cnt on are all flagged).
+#pragma unroll
+    for (uint32_t j = 0; j < BS_E; j++) {
+        const uint64_t nx = s_f[j * SK_NW + wave + 1];
+        const uint64_t mk = ~(fm[j] & ((fm[j] >> 1) | (nx << 63)));
+        if (mk) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_m[0], (uint32_t)__popcll(mk));
+            base = bzx_bcast0(base);
+            if ((mk >> lane) & 1ull) LIST(0, base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))) = (uint16_t)(j * SK_NT + tid);
+        }
     }
 }
 
@@ -953,14 +976,19 @@ __device__ __forceinline__ uint32_t *rank_array(const BzxBatch &B, uint32_t k)
 __device__ __forceinline__ void bsort_body(const BzxBatch &B)
 {
     const uint32_t tid0 = threadIdx.x;
-    const uint32_t n_items = B.counters[BZX_CTR_BK_ITEMS] < B.bk_cap ? B.counters[BZX_CTR_BK_ITEMS] : B.bk_cap;
     if (B.bsort_mode == 1 && B.counters[BZX_CTR_RESUME] == 0) return;          // fill pass: no block needs it
     DIAG_T0();
-    // Work items are dealt round-robin (workgroup g sorts items g, g+G, ..: ~250 buckets each, so the load evens out
-    // without an atomic fetch on the critical path), which makes the NEXT item known early: its descriptor is loaded
-    // two iterations ahead and its records travel in registers while the current bucket is sorted.
-    const uint32_t G = gridDim.x;
-    uint32_t idx = blockIdx.x;
+    // Work items: eight lists; workgroup g takes the items g/8, g/8 + G/8, .. of list g % 8 (~250 buckets each, so the
+    // load evens out without an atomic fetch on the critical path).  The workgroups with equal g % 8 share an XCD, and
+    // in a batch of many blocks a list holds whole blocks: every gather from a block's packed text then goes through
+    // the same L2 (dealt over all XCDs, half of the gathers missed L2: rocprofv3 TCC_MISS).  The fixed order also makes
+    // the NEXT item known early: its descriptor is loaded two iterations ahead and its records travel in registers
+    // while the current bucket is sorted.
+    const uint32_t G = gridDim.x >> 3;                                         // (the grid is a multiple of 8)
+    const uint32_t cap8 = B.bk_cap >> 3, lx = blockIdx.x & 7u;
+    const uint32_t n_lx = B.counters[BZX_CTR_BK_LIST0 + lx] < cap8 ? B.counters[BZX_CTR_BK_LIST0 + lx] : cap8;
+    const uint32_t n_items = lx * cap8 + n_lx;                                 // end of my list
+    uint32_t idx = lx * cap8 + (blockIdx.x >> 3);
     BzxBucket it = {0, 0, 0, 0}, nit = {0, 0, 0, 0};
     if (idx < n_items) it = uni(B.bk_list[idx]);
     if (idx + G < n_items) nit = uni(B.bk_list[idx + G]);
@@ -1044,8 +1072,7 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
         uint32_t dcur = depth0 + BS_KEYBITS;
         bool fail = false;
         uint32_t lpar = 0;
-        list_tied<true>(cnt, 0, 0);
-        __syncthreads();
+        __syncthreads();                                          // (list 0: written by initial_sort)
         DIAG_STAMP(73);
         for (uint32_t round = 0;; round++) {
             tid = tid_here();
@@ -1243,14 +1270,27 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
             }
         }
         {
+            // the bucket's rows of the last column: a lane takes BS_E consecutive ranks and writes their bytes with one
+            // store (one byte per lane and store made the write path move 64 B per wave instruction: WRITE_SIZE was six
+            // times the bytes written)
+            static_assert(BS_E == 8, "eight ranks per lane, one 8-byte store");
             uint8_t *__restrict__ L = B.bwt + BZX_SLAB(B, b) * BZX_BLK_STRIDE + start;
+            const uint32_t p0 = tid * BS_E;
+            if (p0 < cnt) {
+                uint64_t w8[BS_E];
 #pragma unroll
-            for (uint32_t j = 0; j < BS_E; j++) {
-                const uint32_t p = j * SK_NT + tid;
-                if (p < cnt) {
-                    const uint64_t r = s_x[(uint32_t)(s_w[p] & W_POS_MASK)];
-                    L[p] = (uint8_t)REC_PREV(r);
-                    if (REC_IDX(r) == 0) B.blk[b].orig_ptr = start + p;
+                for (uint32_t k = 0; k < BS_E; k++) w8[k] = s_w[p0 + k];
+                uint64_t bytes = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < BS_E; k++) {
+                    const uint32_t r = reinterpret_cast<const uint32_t *>(s_x)[2u * (uint32_t)(w8[k] & W_POS_MASK)];   // (low half of the record)
+                    bytes |= (uint64_t)REC_PREV(r) << (8 * k);
+                    if (p0 + k < cnt && REC_IDX(r) == 0) B.blk[b].orig_ptr = start + p0 + k;
+                }
+                if (p0 + BS_E <= cnt) {
+                    __builtin_memcpy(L + p0, &bytes, 8);
+                } else {
+                    for (uint32_t k = 0; p0 + k < cnt; k++) L[p0 + k] = (uint8_t)(bytes >> (8 * k));
                 }
             }
             DIAG_COUNT(83, 1);
@@ -1579,6 +1619,7 @@ void bzx_launch_bsplit(const BzxBatch &B, uint32_t grid, hipStream_t stream)
 
 void bzx_launch_bsort(const BzxBatch &B, uint32_t grid, hipStream_t stream)
 {
+    grid = grid < 8 ? 8 : grid & ~7u;              // eight work lists, workgroup g on list g % 8
     if (B.bsort_mode == 1) hipLaunchKernelGGL(bzx_bfill_kernel, dim3(grid), dim3(SK_NT), 0, stream, B);
     else hipLaunchKernelGGL(bzx_bsort_kernel, dim3(grid), dim3(SK_NT), 0, stream, B);
 }

@@ -28,7 +28,8 @@
 
 // counters[] slots (BzxBatch.counters, zeroed per batch)
 #define BZX_CTR_PERIODIC 5         // blocks flagged periodic
-#define BZX_CTR_BK_ITEMS 8         // bucket work items produced by the split kernel
+#define BZX_CTR_BK_ITEMS 8         // (unused since the work list became eight lists)
+#define BZX_CTR_BK_LIST0 40        // [40..47] bucket work items in each of the eight lists (BzxBatch.bk_list)
 #define BZX_CTR_BK_FETCH 9         // ... fetched by the bucket sort kernel
 #define BZX_CTR_REDO 10            // blocks handed to the general sorter
 #define BZX_CTR_SPLIT_FETCH 11     // blocks fetched by the split kernel
@@ -110,8 +111,13 @@ struct BzxBatch {
     uint8_t *pk;            // [nblk][BZX_PK_STRIDE]   packed blocks (bucket sorter)
     uint64_t *rec_a;        // [nblk][BZX_MAX_N]       bucket records
     uint64_t *rec_b;        // [nblk][BZX_MAX_N]       ... of the deeper split levels
-    BzxBucket *bk_list;     // [bk_cap] bucket work items (zeroed per batch)
-    uint32_t bk_cap;
+    BzxBucket *bk_list;     // [bk_cap] bucket work items (zeroed per batch): EIGHT lists of bk_cap / 8 items.  Workgroup g of the
+                            // sort kernel works through list g % 8 -- the workgroups that share an XCD (MI355X deals workgroups
+                            // round-robin over its 8 XCDs) -- and with bk_affine every block keeps all its buckets in one list,
+                            // so the block's packed text, which its ~660 buckets gather from, is fetched into ONE L2
+    uint32_t bk_cap;        // capacity of this launch (a multiple of 8)
+    uint32_t bk_affine;     // 1: block j -> list j % 8 (batches of many blocks); 0: the buckets of a block are dealt over all
+                            // eight lists (few blocks: every compute unit must get work)
     uint32_t *redo_list;    // [nblk] blocks for the general sorter
     uint32_t *resume_list;  // [nblk] blocks the general sorter finishes (BZX_ST_RESUME)
     uint32_t *rk_list;      // [bk_cap] indices into bk_list of the buckets that gave up

@@ -1,10 +1,10 @@
 """Ad-hoc GPU probe: sums the SQ counters of a rocprofv3 --pmc run per kernel (counter_collection.csv -> table).
 
     python tests/gpu_probe_sq.py <dir with *_counter_collection.csv> [out.csv]"""
-import csv, glob, sys
+import csv, glob, os, sys
 from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(float)); calls = defaultdict(int)
-for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
