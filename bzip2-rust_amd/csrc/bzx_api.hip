@@ -986,6 +986,7 @@ extern "C" int bzx_cstream_feed(struct bzx_cstream *s, const uint8_t *raw, size_
                                 size_t *produced);
 extern "C" void bzx_cstream_end(struct bzx_cstream *s);
 static int cstream_reset(struct bzx_cstream *s, int level);
+static int cstream_collect_finish(struct bzx_cstream *s);
 static size_t cstream_chunk_of(const struct bzx_cstream *s);
 static size_t cstream_need_hint(const struct bzx_cstream *s);
 
@@ -999,8 +1000,11 @@ extern "C" int bzx_compress_buffer(bzx_ctx *ctx, const uint8_t *raw, size_t len,
     if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
     if (!ctx || !out || !out_len || !level_ok(level) || (len && !raw) || cap < 16) return BZX_E_PARAM;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // chunk: 16 MiB doubling up to 128 MiB, then one block per compute unit (256 x 900,000 B on MI355X): the kernels that
+    // give a block one workgroup then run whole rounds (299 blocks of a 256 MiB chunk were 1.17 rounds, paid as two)
     size_t chunk = (size_t)16 << 20;
-    while (chunk < len && chunk < ((size_t)256 << 20)) chunk <<= 1;
+    while (chunk < len && chunk < ((size_t)128 << 20)) chunk <<= 1;
+    if (chunk < len) chunk = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 900000u;
     int rc;
     if (ctx->cs && cstream_chunk_of(ctx->cs) < chunk) {
         bzx_cstream_end(ctx->cs);
@@ -1250,11 +1254,10 @@ extern "C" int bzx_shard_assemble_rank(bzx_ctx *ctx, const void *d_packed_r, uin
 // ---- decompression (include/bzx.h: bzx_decompress_*; kernels in bzx_decomp.hip) ----------------------------------
 #define DC_MAX_FOUND 262144u
 
-extern "C" int bzx_decompress_device(bzx_ctx *ctx, const void *d_bz2, size_t len, void *d_out, size_t cap, size_t *out_len)
+// One bzip2 stream at the start of d_bz2[0..len); *consumed = bytes up to and including its footer.
+static int decompress_one(bzx_ctx *ctx, const void *d_bz2, size_t len, void *d_out, size_t cap, size_t *out_len, size_t *consumed)
 {
-    std::unique_lock<std::recursive_mutex> api_lock_;
-    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
-    if (!ctx || !d_bz2 || !out_len || (cap && !d_out) || ((uintptr_t)d_out & 15u)) return BZX_E_PARAM;
+    *consumed = 0;
     if (!ctx->use_bsort) {
         ctx->err = "decompression needs the bucket sorter's buffers (BZX_SORTER=general is set)";
         return BZX_E_STATE;
@@ -1410,9 +1413,37 @@ extern "C" int bzx_decompress_device(bzx_ctx *ctx, const void *d_bz2, size_t len
         return BZX_E_DATA;
     }
     *out_len = (size_t)total;
+    *consumed = (size_t)((end_bit + 80 + 7) / 8);
     ctx->stats.nblk = nblk;
     ctx->stats.raw_bytes = total;
     return BZX_OK;
+}
+
+// true when another stream header (BZh1..BZh9) starts at d_bz2[at]
+static bool stream_follows(bzx_ctx *ctx, const void *d_bz2, size_t len, size_t at)
+{
+    uint8_t h[4] = {0, 0, 0, 0};
+    if (at + 14 > len) return false;
+    if (hipMemcpy(h, (const uint8_t *)d_bz2 + at, 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return h[0] == 'B' && h[1] == 'Z' && h[2] == 'h' && h[3] >= '1' && h[3] <= '9';
+}
+
+// Device buffer -> device buffer: ONE stream (the reference's decompress() also stops at the first footer,
+// decompress.rs:81-95).  Bytes behind the footer that are not another stream are ignored, as bzip2 does ("trailing
+// garbage"); a concatenated .bz2 (pbzip2 output, cat a.bz2 b.bz2) is refused here rather than decoded in part --
+// bzx_decompress_buffer decodes every stream of it.
+extern "C" int bzx_decompress_device(bzx_ctx *ctx, const void *d_bz2, size_t len, void *d_out, size_t cap, size_t *out_len)
+{
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
+    if (!ctx || !d_bz2 || !out_len || (cap && !d_out) || ((uintptr_t)d_out & 15u)) return BZX_E_PARAM;
+    size_t used = 0;
+    const int rc = decompress_one(ctx, d_bz2, len, d_out, cap, out_len, &used);
+    if (rc == BZX_OK && stream_follows(ctx, d_bz2, len, used)) {
+        ctx->err = "another bzip2 stream follows the first (concatenated .bz2): bzx_decompress_buffer decodes all of them";
+        return BZX_E_DATA;
+    }
+    return rc;
 }
 
 extern "C" int bzx_decompress_buffer(bzx_ctx *ctx, const uint8_t *bz2, size_t len, uint8_t *out, size_t cap, size_t *out_len)
@@ -1428,10 +1459,42 @@ extern "C" int bzx_decompress_buffer(bzx_ctx *ctx, const uint8_t *bz2, size_t le
         return BZX_E_NOMEM;
     }
     int rc = hipMemcpyAsync(d_z, bz2, len, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? BZX_OK : BZX_E_HIP;
-    if (!rc) rc = bzx_decompress_device(ctx, d_z, len, d_o, cap, out_len);
-    if (!rc && *out_len && hipMemcpy(out, d_o, *out_len, hipMemcpyDeviceToHost) != hipSuccess) rc = BZX_E_HIP;
+    // every stream of a concatenated .bz2, one after the other (each stream starts on a byte boundary)
+    size_t at = 0, total = 0;
+    uint32_t nblk_all = 0;
+    *out_len = 0;
+    void *d_z2 = nullptr;                          // a later stream, moved to an aligned start (the kernels read words)
+    while (!rc) {
+        size_t n = 0, used = 0;
+        const void *src = d_z;
+        if (at) {
+            if (!d_z2 && hipMalloc(&d_z2, len + 64) != hipSuccess) {
+                rc = BZX_E_NOMEM;
+                break;
+            }
+            if (hipMemcpyAsync(d_z2, (const uint8_t *)d_z + at, len - at, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+                rc = BZX_E_HIP;
+                break;
+            }
+            src = d_z2;
+        }
+        rc = decompress_one(ctx, src, len - at, d_o, cap - total, &n, &used);
+        if (rc == BZX_E_OUTBUF) *out_len = total + n;          // (a lower bound when streams remain)
+        if (rc) break;
+        if (n && hipMemcpy(out + total, d_o, n, hipMemcpyDeviceToHost) != hipSuccess) rc = BZX_E_HIP;
+        total += n;
+        nblk_all += ctx->stats.nblk;
+        at += used;
+        *out_len = total;
+        if (!stream_follows(ctx, d_z, len, at)) break;
+    }
+    if (!rc) {
+        ctx->stats.nblk = nblk_all;
+        ctx->stats.raw_bytes = total;
+    }
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_z);
+    if (d_z2) (void)hipFree(d_z2);
     (void)hipFree(d_o);
     return rc;
 }
@@ -1540,6 +1603,7 @@ struct bzx_cstream {
     uint64_t nblk_total = 0, st_rle1 = 0, st_mtf = 0, st_raw = 0;
     uint32_t st_per = 0;
     bool pend = false;                      // a chunk's output still sits in d_out[pend_slot]
+    bool coll_issued = false;               // ... and its copy-back has been enqueued (cstream_collect), not yet awaited
     uint32_t pend_slot = 0, pend_nblk = 0;
     bool finished = false;
     uint8_t *out = nullptr;
@@ -1586,10 +1650,13 @@ extern "C" int bzx_cstream_begin(bzx_ctx *ctx, int level, size_t max_chunk, bzx_
     s->ctx = ctx;
     s->level = level;
     s->max_chunk = max_chunk;
-    s->in_cap = max_chunk + cstream_max_carry(level) + 256;
+    // Sized for EVERY level, not the one given here: bzx_compress_buffer keeps the stream object in the context and
+    // starts the next stream on it at whatever level its caller asks for (cstream_reset) -- the withheld raw tail is
+    // longest at level 9, the blocks of a chunk are most numerous at level 1.
+    s->in_cap = max_chunk + cstream_max_carry(9) + 256;
     s->out_cap = (s->in_cap + s->in_cap / 50 + 65536) & ~(size_t)255;       // RLE1 +25 % never survives coding: 2 % + slack
     s->out_cap += s->in_cap / 4;
-    s->blk_cap = (uint32_t)((s->in_cap + s->in_cap / 4) / ((size_t)100000 * level - 19) + 4);
+    s->blk_cap = (uint32_t)((s->in_cap + s->in_cap / 4) / ((size_t)100000 * 1 - 19) + 4);
     bool ok = true;
     for (int i = 0; i < 2 && ok; i++) {
         ok = hipMalloc((void **)&s->d_in[i], s->in_cap) == hipSuccess && hipMalloc((void **)&s->d_out[i], s->out_cap) == hipSuccess &&
@@ -1645,6 +1712,22 @@ static int cstream_collect(bzx_cstream *s)
             HIP_TRY(ctx, hipMemcpyAsync(s->out + off + 4, s->d_out[slot] + 1, (nwords - 1) * 4, hipMemcpyDeviceToHost, s->s_d2h));
     }
     HIP_TRY(ctx, hipEventRecord(s->ev_d2h, s->s_d2h));
+    s->coll_issued = true;
+    return BZX_OK;
+}
+
+// Second half: waits for the copy-back issued by cstream_collect, merges the word the chunk shares with its
+// predecessor and folds its block CRCs.  Called AFTER the next chunk's stages have been enqueued, so the copy-back of
+// chunk k-1 runs beside the compression of chunk k.
+static int cstream_collect_finish(bzx_cstream *s)
+{
+    bzx_ctx *ctx = s->ctx;
+    if (!s->pend || !s->coll_issued) return BZX_OK;
+    s->coll_issued = false;
+    const uint32_t slot = s->pend_slot;
+    const uint64_t phase = s->bits & 31u, cbits = s->h_info[slot][1];
+    const uint64_t nwords = (phase + cbits + 31) >> 5;
+    const size_t off = (size_t)(s->bits >> 5) * 4;
     HIP_TRY(ctx, hipEventSynchronize(s->ev_d2h));
     if (nwords) {
         // the first word is shared with the predecessor (or with nothing: then the bytes there are still zero)
@@ -1687,6 +1770,7 @@ static int cstream_reset(bzx_cstream *s, int level)
     s->nblk_total = s->st_rle1 = s->st_mtf = s->st_raw = 0;
     s->st_per = 0;
     s->pend = false;
+    s->coll_issued = false;
     s->finished = false;
     return BZX_OK;
 }
@@ -1707,6 +1791,10 @@ extern "C" int bzx_cstream_feed(bzx_cstream *s, const uint8_t *raw, size_t len, 
     s->cap = cap;
     const uint32_t slot = s->k & 1u;
     const size_t total = s->carry_len + len;
+    if (total > s->in_cap) {                     // (cannot happen with the provisioning above; never write past d_in)
+        ctx->err = "chunked stream: withheld bytes + chunk exceed the device input buffer";
+        return BZX_E_STATE;
+    }
     // the device buffer of this slot was last read by chunk k-2; its kernels are long done when k-1's results were
     // collected, but the copy stream does not know that: make it wait
     if (s->k >= 2) HIP_TRY(ctx, hipStreamWaitEvent(s->s_h2d, s->ev_done[slot], 0));
@@ -1734,13 +1822,17 @@ extern "C" int bzx_cstream_feed(bzx_cstream *s, const uint8_t *raw, size_t len, 
     }
     // the previous chunk was laid out before this chunk's split ran: its sizes are on the host now
     if (!total) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if ((rc = cstream_collect(s))) return rc;
+    // Chunk k's stages go into the queue FIRST; then the copy-back of chunk k-1 is issued on its own stream and awaited:
+    // it runs beside the compression of chunk k (with a pageable destination the runtime stages the copy and blocks the
+    // host while it lasts -- the device has its work by then).
     if (use) {
         if ((rc = run_stages(ctx, use, STG_ALL, -1, s->d_out[slot], s->out_cap, s->d_phase))) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(s->h_info[slot], s->d_phase, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(s->h_blk[slot], ctx->B.blk, (size_t)use * sizeof(BzxBlock), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(ctx, hipEventRecord(s->ev_done[slot], ctx->stream));
+    if ((rc = cstream_collect(s))) return rc;
+    if ((rc = cstream_collect_finish(s))) return rc;
     if (use) {
         s->pend = true;
         s->pend_slot = slot;
@@ -1757,6 +1849,7 @@ extern "C" int bzx_cstream_feed(bzx_cstream *s, const uint8_t *raw, size_t len, 
     if (final) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if ((rc = cstream_collect(s))) return rc;
+        if ((rc = cstream_collect_finish(s))) return rc;
         collect_stage_times(ctx);
         // footer: magic, combined CRC (crc.rs:25-27), zero padding to a byte (bitwriter.rs:103-114,158-172)
         const uint64_t end = s->bits;

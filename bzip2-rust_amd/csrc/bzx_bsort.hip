@@ -1270,24 +1270,24 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
             }
         }
         {
-            // the bucket's rows of the last column: a lane takes BS_E consecutive ranks and writes their bytes with one
+            // the bucket's rows of the last column: a lane takes eight consecutive ranks and writes their bytes with one
             // store (one byte per lane and store made the write path move 64 B per wave instruction: WRITE_SIZE was six
             // times the bytes written)
-            static_assert(BS_E == 8, "eight ranks per lane, one 8-byte store");
+            constexpr uint32_t OUT_E = 8;                          // ranks per lane (lanes beyond BS_C / 8 have none)
             uint8_t *__restrict__ L = B.bwt + BZX_SLAB(B, b) * BZX_BLK_STRIDE + start;
-            const uint32_t p0 = tid * BS_E;
+            const uint32_t p0 = tid * OUT_E;
             if (p0 < cnt) {
-                uint64_t w8[BS_E];
+                uint64_t w8[OUT_E];
 #pragma unroll
-                for (uint32_t k = 0; k < BS_E; k++) w8[k] = s_w[p0 + k];
+                for (uint32_t k = 0; k < OUT_E; k++) w8[k] = s_w[p0 + k];
                 uint64_t bytes = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < BS_E; k++) {
+                for (uint32_t k = 0; k < OUT_E; k++) {
                     const uint32_t r = reinterpret_cast<const uint32_t *>(s_x)[2u * (uint32_t)(w8[k] & W_POS_MASK)];   // (low half of the record)
                     bytes |= (uint64_t)REC_PREV(r) << (8 * k);
                     if (p0 + k < cnt && REC_IDX(r) == 0) B.blk[b].orig_ptr = start + p0 + k;
                 }
-                if (p0 + BS_E <= cnt) {
+                if (p0 + OUT_E <= cnt) {
                     __builtin_memcpy(L + p0, &bytes, 8);
                 } else {
                     for (uint32_t k = 0; p0 + k < cnt; k++) L[p0 + k] = (uint8_t)(bytes >> (8 * k));

@@ -230,6 +230,45 @@ def test_chunked_stream_compressor(bzx, oracle):
     assert bzx.compress_buffer(big, 9) == want
 
 
+def test_levels_change_on_one_context(bzx, oracle):
+    """bzx_compress_buffer keeps its chunked-stream object in the context and starts the next stream on it at whatever
+    level the caller asks for: the object must be provisioned for every level (blocks per chunk are most numerous at
+    level 1: 16 MiB is 168 blocks there, 19 at level 9; the withheld raw tail of a run-heavy chunk is longest at 9)."""
+    text = oracle.synthtext(20 << 20)
+    zeros = b"\0" * (24 << 20) + b"end"
+    for level in (9, 1, 9, 2, 5, 1):
+        assert bzx.compress_buffer(text, level) == bz2.compress(text, level), level
+        assert bzx.compress_buffer(zeros, level) == bz2.compress(zeros, level), level
+
+
+def test_concatenated_streams(bzx, oracle, tmp_path):
+    """A .bz2 made of several streams (pbzip2 output, cat a.bz2 b.bz2): bzx_decompress_buffer decodes every one of
+    them (the reference stops at the first footer, decompress.rs:81-95; bzip2 itself does not); bytes behind the
+    footer that are no stream are ignored, as bzip2 does; and the command line tool never deletes the source after a
+    failed decode."""
+    import subprocess
+    from bzx_ctypes import ROOT, BzxError
+    a, b, c = oracle.synthtext(1_200_000), b"\0" * 70_000 + oracle.randbytes(30_001), b""
+    z = bz2.compress(a, 9) + bz2.compress(b, 1) + bz2.compress(c, 5) + bz2.compress(a[:777], 3)
+    assert bz2.decompress(z) == a + b + c + a[:777]
+    assert bzx.decompress_buffer(z) == a + b + c + a[:777]
+    assert bzx.decompress_buffer(z, cap=1 << 16) == a + b + c + a[:777]          # (grows through BZX_E_OUTBUF)
+    assert bzx.decompress_buffer(bz2.compress(a, 9) + b"\0\0trailing bytes") == a
+    one = bz2.compress(b, 9)
+    bad = bytearray(one + one)
+    bad[len(one) + len(one) // 2] ^= 0x10
+    with pytest.raises(BzxError):
+        bzx.decompress_buffer(bytes(bad))
+    exe = os.path.join(ROOT, "bzip2-rust_amd", "bzx")
+    p = tmp_path / "cat.bz2"
+    p.write_bytes(z)
+    subprocess.check_call([exe, "-d", str(p)])
+    assert (tmp_path / "cat").read_bytes() == a + b + c + a[:777] and not p.exists()
+    p.write_bytes(bytes(bad))
+    assert subprocess.run([exe, "-d", "-f", str(p)], stderr=subprocess.PIPE).returncode != 0
+    assert p.exists() and p.read_bytes() == bytes(bad)                           # the source survives a failed decode
+
+
 def test_chunked_split(bzx, oracle):
     """bzx_split_rle1_chunk == one-shot split, for pieces of any size."""
     runs = (b"\xff" * 1000 + b"abc") * 2500 + b"\0" * 1_000_000 + oracle.synthtext(1_900_000)

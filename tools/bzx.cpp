@@ -221,14 +221,17 @@ int main(int argc, char **argv)
         }
         const int r = o.mode == ZIP ? do_zip(o, ctx, in, out, f.c_str()) : do_unzip(o, ctx, in, out, f.c_str());
         if (!std_in) fclose(in);
+        int wr = 0;                                  // the output is complete on disk only when flush and close succeed
         if (out && out != stdout) {
-            if (fclose(out) != 0) ret = 1;
-            if (r) unlink(oname.c_str());
-            else if (!o.keep) unlink(f.c_str());
+            if (fflush(out) != 0 || ferror(out)) wr = 1;
+            if (fclose(out) != 0) wr = 1;
+            if (wr && !r && !o.quiet) fprintf(stderr, "bzx: %s: %s\n", oname.c_str(), strerror(errno));
+            if (r || wr) unlink(oname.c_str());      // never leave a partial output ...
+            else if (!o.keep) unlink(f.c_str());     // ... and never remove the input unless the output is whole
         } else if (out) {
-            fflush(out);
+            if (fflush(out) != 0 || ferror(out)) wr = 1;
         }
-        ret |= r;
+        ret |= r | wr;
     }
     bzx_ctx_destroy(ctx);
     return ret;
