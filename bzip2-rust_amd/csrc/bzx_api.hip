@@ -33,6 +33,11 @@ void bzx_launch_stream_frame(const BzxBatch &B, int level, const uint64_t *d_tot
                              hipStream_t stream);
 int bzx_split_launch_boundaries(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t max_blocks,
                                 BzxSplitWs *ws_out);
+uint64_t bzx_split_tiles_per_rank(size_t len, uint32_t world);
+int bzx_split_shard_runs(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, uint32_t rank, uint32_t world, uint64_t *tiles);
+int bzx_split_shard_counts(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, uint32_t rank, uint32_t world, uint64_t *tiles);
+int bzx_split_shard_boundaries(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t max_blocks,
+                               uint32_t world, uint64_t *tiles, BzxSplitWs *ws_out);
 void bzx_split_launch_scatter(struct bzx_ctx *ctx, const uint8_t *d_raw, size_t len, const BzxSplitWs &ws,
                               uint32_t nblk, uint8_t *d_slabs, BzxBlock *d_blk, uint32_t own_first, uint32_t own_step);
 void bzx_launch_dc_scan(const uint8_t *z, uint64_t nbytes, uint64_t *found, uint32_t *n_found, uint32_t cap, uint32_t grid,
@@ -899,7 +904,8 @@ static int level_ok(int level) { return level >= 1 && level <= 9; }
 
 // Device split: raw (device) -> block slabs + descriptors (n, crc, in_off).  Returns the block count.
 static int split_on_device(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t *nblk_out,
-                           uint32_t own_first = 0, uint32_t own_step = 1, uint64_t *last_raw_start = nullptr)
+                           uint32_t own_first = 0, uint32_t own_step = 1, uint64_t *last_raw_start = nullptr,
+                           uint64_t *gathered_tiles = nullptr)
 {
     *nblk_out = 0;
     if (len == 0) return BZX_OK;
@@ -910,7 +916,10 @@ static int split_on_device(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int l
     int rc = ensure_blocks(ctx, max_blocks, (max_blocks + own_step - 1) / own_step + 1);
     if (rc) return rc;
     BzxSplitWs ws;
-    if ((rc = bzx_split_launch_boundaries(ctx, d_raw, len, level, max_blocks, &ws))) return rc;
+    // (gathered_tiles: the per-byte scans were done rank by rank, bzx_shard_scan_*; only the chain of boundaries is left)
+    if (gathered_tiles) rc = bzx_split_shard_boundaries(ctx, d_raw, len, level, max_blocks, own_step, gathered_tiles, &ws);
+    else rc = bzx_split_launch_boundaries(ctx, d_raw, len, level, max_blocks, &ws);
+    if (rc) return rc;
     uint32_t *h_n = (uint32_t *)(ctx->h_scalars + 4);
     HIP_TRY(ctx, hipMemcpyAsync(h_n, ws.nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1079,8 +1088,8 @@ extern "C" int bzx_split_rle1(bzx_ctx *ctx, const uint8_t *raw, size_t len, int 
 // ---- multi-GPU sharding: block i belongs to rank i mod world; no collective in here.
 // The caller all-reduces (sum) d_bits between the two calls and sums the partial streams afterwards
 // (torch.distributed / RCCL; see bench.py).  Declared in include/bzx.h.
-extern "C" int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, int level, uint32_t rank, uint32_t world,
-                                 uint32_t *nblk_total, long long *d_bits, size_t bits_cap)
+static int shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, int level, uint32_t rank, uint32_t world,
+                         uint32_t *nblk_total, long long *d_bits, size_t bits_cap, uint64_t *gathered_tiles)
 {
     std::unique_lock<std::recursive_mutex> api_lock_;
     if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
@@ -1090,11 +1099,11 @@ extern "C" int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, in
         return BZX_E_PARAM;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    if (!gathered_tiles) HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));     // (else: bzx_shard_scan_runs did)
     uint32_t nblk = 0;
     ctx->B.blk_first = 0;
     ctx->B.blk_step = 1;
-    int rc = split_on_device(ctx, (const uint8_t *)d_raw, len, level, &nblk, rank, world);
+    int rc = split_on_device(ctx, (const uint8_t *)d_raw, len, level, &nblk, rank, world, nullptr, gathered_tiles);
     if (rc) return rc;
     if (nblk > bits_cap) return BZX_E_OUTBUF;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
@@ -1114,6 +1123,61 @@ extern "C" int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, in
     ctx->shard_len = len;
     *nblk_total = nblk;
     return BZX_OK;
+}
+
+extern "C" int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, int level, uint32_t rank, uint32_t world,
+                                 uint32_t *nblk_total, long long *d_bits, size_t bits_cap)
+{
+    return shard_prepare(ctx, d_raw, len, level, rank, world, nblk_total, d_bits, bits_cap, nullptr);
+}
+
+// ---- sharded split analysis: the two per-byte passes of the block splitter run on 1/world of the
+// input per rank; what the ranks exchange is 24 bytes per 8 KiB tile (the caller's all-gathers).  include/bzx.h.
+static int shard_scan_args(bzx_ctx *ctx, const void *d_raw, size_t len, uint32_t rank, uint32_t world, long long *d_tiles)
+{
+    if (!ctx || !d_tiles || world == 0 || rank >= world || !len || !d_raw) return BZX_E_PARAM;
+    if ((uintptr_t)d_raw & 15u) {
+        ctx->err = "bzx_shard_scan_*: d_raw must be 16-byte aligned";
+        return BZX_E_PARAM;
+    }
+    return BZX_OK;
+}
+
+extern "C" size_t bzx_shard_scan_entries(size_t len, uint32_t world)
+{
+    return world ? (size_t)bzx_split_tiles_per_rank(len, world) : 0;
+}
+
+extern "C" int bzx_shard_scan_runs(bzx_ctx *ctx, const void *d_raw, size_t len, uint32_t rank, uint32_t world, long long *d_tiles)
+{
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
+    int rc = shard_scan_args(ctx, d_raw, len, rank, world, d_tiles);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    rc = bzx_split_shard_runs(ctx, (const uint8_t *)d_raw, len, rank, world, (uint64_t *)d_tiles);
+    HIP_TRY(ctx, hipGetLastError());
+    return rc;
+}
+
+extern "C" int bzx_shard_scan_counts(bzx_ctx *ctx, const void *d_raw, size_t len, uint32_t rank, uint32_t world, long long *d_tiles)
+{
+    std::unique_lock<std::recursive_mutex> api_lock_;
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>(ctx->api_mu);
+    int rc = shard_scan_args(ctx, d_raw, len, rank, world, d_tiles);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = bzx_split_shard_counts(ctx, (const uint8_t *)d_raw, len, rank, world, (uint64_t *)d_tiles);
+    HIP_TRY(ctx, hipGetLastError());
+    return rc;
+}
+
+extern "C" int bzx_shard_prepare_scanned(bzx_ctx *ctx, const void *d_raw, size_t len, int level, uint32_t rank, uint32_t world,
+                                         long long *d_tiles, uint32_t *nblk_total, long long *d_bits, size_t bits_cap)
+{
+    if (!d_tiles || !len) return BZX_E_PARAM;
+    return shard_prepare(ctx, d_raw, len, level, rank, world, nblk_total, d_bits, bits_cap, (uint64_t *)d_tiles);
 }
 
 extern "C" int bzx_ctx_sync(bzx_ctx *ctx)

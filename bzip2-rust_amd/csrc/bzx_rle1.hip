@@ -95,10 +95,11 @@ __device__ __forceinline__ uint64_t block_excl_max64(uint64_t v, uint64_t *scrat
 
 // ---- A: last run start per tile
 __global__ __launch_bounds__(RL_NT) void bzx_rl_runstart_kernel(const uint8_t *__restrict__ raw, uint64_t len,
-                                                                uint64_t ntiles, BzxSplitWs ws)
+                                                                uint64_t t_lo, uint64_t ntiles, BzxSplitWs ws)
 {
+    // tiles [t_lo, ntiles): all of them, or one rank's share of a sharded analysis (bzx_shard_scan_runs)
     __shared__ uint64_t scratch[RL_NT / 64];
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (uint64_t tile = t_lo + blockIdx.x; tile < ntiles; tile += gridDim.x) {
         TileLane t;
         bool run4 = true;                   // "this tile may hold a run position k >= 3": decided exactly by kernel B
         if (tile > 0 && (tile + 1) * RL_TILE <= len) {
@@ -295,7 +296,7 @@ __device__ __forceinline__ void tile_analyse(const uint8_t *__restrict__ raw, ui
 
 // ---- B: emitted bytes per tile
 __global__ __launch_bounds__(RL_NT) void bzx_rl_count_kernel(const uint8_t *__restrict__ raw, uint64_t len,
-                                                             uint64_t ntiles, BzxSplitWs ws)
+                                                             uint64_t t_lo, uint64_t ntiles, BzxSplitWs ws)
 {
     __shared__ uint64_t s64[RL_NT / 64];
     __shared__ uint32_t s32[RL_NT / 64];
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(RL_NT) void bzx_rl_count_kernel(const uint8_t *__re
     // takes 256 tiles at a time (one flag per lane, coalesced) and walks the flagged ones.
     __shared__ uint32_t s_list[RL_NT];
     __shared__ uint32_t s_cnt;
-    for (uint64_t base = (uint64_t)blockIdx.x * RL_NT; base < ntiles; base += (uint64_t)gridDim.x * RL_NT) {
+    for (uint64_t base = t_lo + (uint64_t)blockIdx.x * RL_NT; base < ntiles; base += (uint64_t)gridDim.x * RL_NT) {
         if (threadIdx.x == 0) s_cnt = 0;
         __syncthreads();
         {
@@ -756,32 +757,123 @@ int bzx_ctx_split_scratch(bzx_ctx *ctx, size_t bytes, void **p);   // bzx_api.hi
 hipStream_t bzx_ctx_stream(bzx_ctx *ctx);
 int bzx_ctx_ncu(bzx_ctx *ctx);
 
+// Scratch of the splitter: the three tile arrays (in the context's scratch, or -- sharded analysis -- in the caller's
+// array `tiles` of 3 x tile_stride words, which the ranks all-gather), the block arrays and the scans' segment totals.
+static int split_ws(bzx_ctx *ctx, size_t len, uint32_t max_blocks, uint64_t *tiles, size_t tile_stride, BzxSplitWs *ws_out,
+                    uint64_t **segtot_out)
+{
+    const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE;
+    const uint64_t nsegw = ntiles / SCAN_SEG + 4;                         // scratch of the two-level scans
+    const size_t own_tiles = tiles ? 0 : 3 * (ntiles + 2);
+    const size_t bytes = (own_tiles + 3 * ((size_t)max_blocks + 2) + nsegw + 8) * sizeof(uint64_t) + 64;
+    void *p = nullptr;
+    int rc = bzx_ctx_split_scratch(ctx, bytes, &p);
+    if (rc) return rc;
+    BzxSplitWs ws;
+    uint64_t *q = (uint64_t *)p;
+    if (tiles) {
+        ws.tile_rs = tiles;
+        ws.tile_off = tiles + tile_stride;
+        ws.tile_np = tiles + 2 * tile_stride;
+    } else {
+        ws.tile_rs = q;
+        ws.tile_off = ws.tile_rs + (ntiles + 2);
+        ws.tile_np = ws.tile_off + (ntiles + 2);
+        q = ws.tile_np + (ntiles + 2);
+    }
+    ws.blk_raw = q;
+    ws.blk_f = ws.blk_raw + (max_blocks + 2);
+    ws.blk_plain = (uint32_t *)(ws.blk_f + (max_blocks + 2));
+    ws.nblk = (uint32_t *)((uint64_t *)ws.blk_plain + (max_blocks + 2));
+    *segtot_out = (uint64_t *)ws.nblk + 8;
+    ws.max_blocks = max_blocks;
+    *ws_out = ws;
+    return 0;
+}
+
+static uint32_t tile_grid(bzx_ctx *ctx, uint64_t ntiles)
+{
+    const uint64_t g = (uint64_t)bzx_ctx_ncu(ctx) * 8;
+    return (uint32_t)(ntiles < g ? (ntiles ? ntiles : 1) : g);
+}
+
 // Launches A..C; writes the block count to ws.nblk (device).  max_blocks bounds the descriptor arrays.
 int bzx_split_launch_boundaries(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t max_blocks,
                                 BzxSplitWs *ws_out)
 {
     const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE;
-    const uint64_t nsegw = ntiles / SCAN_SEG + 4;                         // scratch of the two-level scans
-    const size_t bytes = (3 * (ntiles + 2) + 3 * ((size_t)max_blocks + 2) + nsegw) * sizeof(uint64_t) + 64;
-    void *p = nullptr;
-    int rc = bzx_ctx_split_scratch(ctx, bytes, &p);
-    if (rc) return rc;
     BzxSplitWs ws;
-    ws.tile_rs = (uint64_t *)p;
-    ws.tile_off = ws.tile_rs + (ntiles + 2);
-    ws.tile_np = ws.tile_off + (ntiles + 2);
-    ws.blk_raw = ws.tile_np + (ntiles + 2);
-    ws.blk_f = ws.blk_raw + (max_blocks + 2);
-    ws.blk_plain = (uint32_t *)(ws.blk_f + (max_blocks + 2));
-    ws.nblk = (uint32_t *)((uint64_t *)ws.blk_plain + (max_blocks + 2));
-    uint64_t *segtot = (uint64_t *)ws.nblk + 8;
-    ws.max_blocks = max_blocks;
+    uint64_t *segtot = nullptr;
+    int rc = split_ws(ctx, len, max_blocks, nullptr, 0, &ws, &segtot);
+    if (rc) return rc;
     hipStream_t st = bzx_ctx_stream(ctx);
-    const uint32_t grid = (uint32_t)(ntiles < (uint64_t)bzx_ctx_ncu(ctx) * 8 ? ntiles : (uint64_t)bzx_ctx_ncu(ctx) * 8);
+    const uint32_t grid = tile_grid(ctx, ntiles);
     const uint32_t nmax = 100000u * (uint32_t)level - 19u;
-    hipLaunchKernelGGL(bzx_rl_runstart_kernel, dim3(grid), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, ws);
+    hipLaunchKernelGGL(bzx_rl_runstart_kernel, dim3(grid), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, (uint64_t)0, ntiles, ws);
     launch_scan(st, ws.tile_rs, ntiles, 1, segtot);
-    hipLaunchKernelGGL(bzx_rl_count_kernel, dim3(grid), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, ws);
+    hipLaunchKernelGGL(bzx_rl_count_kernel, dim3(grid), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, (uint64_t)0, ntiles, ws);
+    launch_scan(st, ws.tile_off, ntiles, 0, segtot);
+    launch_scan(st, ws.tile_np, ntiles, 0, segtot);
+    hipLaunchKernelGGL(bzx_rl_boundaries_kernel, dim3(1), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, nmax, ws);
+    *ws_out = ws;
+    return 0;
+}
+
+// ---- the same analysis with the per-byte scans (kernels A and B) on one rank's share of the tiles.
+// Tile arrays: the caller's `tiles`, 3 arrays of `stride` = per_rank * world words; rank r owns the entries
+// [r * per_rank, (r + 1) * per_rank) of each and all-gathers them between the steps (the library has no collective).
+uint64_t bzx_split_tiles_per_rank(size_t len, uint32_t world)
+{
+    const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE;
+    return (ntiles + 2 + world - 1) / world;
+}
+
+// step 1: kernel A on this rank's tiles (all three arrays get their provisional entries)
+int bzx_split_shard_runs(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, uint32_t rank, uint32_t world, uint64_t *tiles)
+{
+    const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE, per = bzx_split_tiles_per_rank(len, world);
+    const uint64_t lo = (uint64_t)rank * per < ntiles ? (uint64_t)rank * per : ntiles;
+    const uint64_t hi = lo + per < ntiles ? lo + per : ntiles;
+    BzxSplitWs ws;
+    uint64_t *segtot = nullptr;
+    int rc = split_ws(ctx, len, 2, tiles, per * world, &ws, &segtot);
+    if (rc) return rc;
+    if (hi > lo)
+        hipLaunchKernelGGL(bzx_rl_runstart_kernel, dim3(tile_grid(ctx, hi - lo)), dim3(RL_NT), 0, bzx_ctx_stream(ctx), d_raw,
+                           (uint64_t)len, lo, hi, ws);
+    return 0;
+}
+
+// step 2 (array 0 gathered): carry-in scan over ALL tiles (every rank the same, 8 B per 8 KiB of input), kernel B on
+// this rank's tiles
+int bzx_split_shard_counts(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, uint32_t rank, uint32_t world, uint64_t *tiles)
+{
+    const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE, per = bzx_split_tiles_per_rank(len, world);
+    const uint64_t lo = (uint64_t)rank * per < ntiles ? (uint64_t)rank * per : ntiles;
+    const uint64_t hi = lo + per < ntiles ? lo + per : ntiles;
+    BzxSplitWs ws;
+    uint64_t *segtot = nullptr;
+    int rc = split_ws(ctx, len, 2, tiles, per * world, &ws, &segtot);
+    if (rc) return rc;
+    hipStream_t st = bzx_ctx_stream(ctx);
+    launch_scan(st, ws.tile_rs, ntiles, 1, segtot);
+    if (hi > lo)
+        hipLaunchKernelGGL(bzx_rl_count_kernel, dim3(tile_grid(ctx, (hi - lo + RL_NT - 1) / RL_NT)), dim3(RL_NT), 0, st, d_raw,
+                           (uint64_t)len, lo, hi, ws);
+    return 0;
+}
+
+// step 3 (arrays 1 and 2 gathered): offsets and the serial chain of block boundaries, on every rank
+int bzx_split_shard_boundaries(bzx_ctx *ctx, const uint8_t *d_raw, size_t len, int level, uint32_t max_blocks, uint32_t world,
+                               uint64_t *tiles, BzxSplitWs *ws_out)
+{
+    const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE, per = bzx_split_tiles_per_rank(len, world);
+    BzxSplitWs ws;
+    uint64_t *segtot = nullptr;
+    int rc = split_ws(ctx, len, max_blocks, tiles, per * world, &ws, &segtot);
+    if (rc) return rc;
+    hipStream_t st = bzx_ctx_stream(ctx);
+    const uint32_t nmax = 100000u * (uint32_t)level - 19u;
     launch_scan(st, ws.tile_off, ntiles, 0, segtot);
     launch_scan(st, ws.tile_np, ntiles, 0, segtot);
     hipLaunchKernelGGL(bzx_rl_boundaries_kernel, dim3(1), dim3(RL_NT), 0, st, d_raw, (uint64_t)len, ntiles, nmax, ws);

@@ -129,6 +129,23 @@ int bzx_compress_buffer(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level,
  */
 int bzx_shard_prepare(bzx_ctx *ctx, const void *d_raw, size_t len, int level, uint32_t rank, uint32_t world,
                       uint32_t *nblk_total, long long *d_bits, size_t bits_cap);
+/*
+ * The same with the split ANALYSIS sharded too (the reference's producer touches every byte once,
+ * rle1.rs:89-223): the two per-byte passes of the block splitter -- run starts, and RLE1 byte counts of the 8 KiB tiles
+ * that hold runs -- run on this rank's 1/world share of the tiles only; the ranks exchange 24 bytes per tile, and only
+ * the chain of block boundaries (a serial dependency over the stream, libbz2's split rule) is walked by every rank.
+ * d_tiles: int64[3 * P * world] on every rank, P = bzx_shard_scan_entries(len, world); array a (a = 0, 1, 2) starts at
+ * d_tiles + a * P * world and rank r owns its entries [r * P, (r + 1) * P).
+ *   1a. bzx_shard_scan_runs      then caller: all-gather, in place, of the rank's P entries of array 0
+ *   1b. bzx_shard_scan_counts    then caller: all-gather, in place, of the rank's P entries of arrays 1 and 2
+ *   1c. bzx_shard_prepare_scanned = bzx_shard_prepare without the per-byte passes; steps 2..5 as above.
+ * A rank reads the raw bytes of its own tiles (plus the 4 bytes before them) in 1a/1b and of its own blocks afterwards.
+ */
+size_t bzx_shard_scan_entries(size_t len, uint32_t world);
+int bzx_shard_scan_runs(bzx_ctx *ctx, const void *d_raw, size_t len, uint32_t rank, uint32_t world, long long *d_tiles);
+int bzx_shard_scan_counts(bzx_ctx *ctx, const void *d_raw, size_t len, uint32_t rank, uint32_t world, long long *d_tiles);
+int bzx_shard_prepare_scanned(bzx_ctx *ctx, const void *d_raw, size_t len, int level, uint32_t rank, uint32_t world,
+                              long long *d_tiles, uint32_t *nblk_total, long long *d_bits, size_t bits_cap);
 int bzx_shard_emit_packed(bzx_ctx *ctx, const long long *d_bits_all, void *d_packed, size_t cap, size_t *packed_len,
                           size_t *stream_len);
 /* After bzx_shard_emit_packed: bytes of the longest packed buffer of any rank -- the common length a gather needs --

@@ -33,6 +33,18 @@ def main():
         t = o.synthtext(nbytes // 2)
         mix = t[: nbytes // 4] + t[1000:40000] + t[nbytes // 4:] + t[2000:30000] + t[: nbytes // 3]
         data = np.frombuffer(mix[:nbytes], dtype=np.uint8).copy()
+    elif kind == "border":
+        # runs longer than 255 that straddle the borders between the ranks' tile shares of the sharded analysis, a run
+        # that ends exactly at a border and one that starts there (tiles are 8 KiB)
+        data = np.frombuffer(o.synthtext(nbytes), dtype=np.uint8).copy()
+        per = ((nbytes + 8191) // 8192 + 2 + world - 1) // world
+        for r in range(1, world):
+            b = r * per * 8192
+            if b + 2000 < nbytes:
+                data[b - 300:b + 400] = 0xAA
+                if r % 2 == 0:
+                    data[b - 300:b] = 0x55
+                    data[b:b + 260] = 0x56
     else:
         data = np.frombuffer(o.synthtext(nbytes), dtype=np.uint8).copy()
     raw = np.zeros(data.nbytes + 64, dtype=np.uint8)
@@ -48,8 +60,29 @@ def main():
     L.bzx_shard_assemble_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     bits = torch.zeros(64, dtype=torch.int64)
     nblk = C.c_uint32()
-    lib._check(L.bzx_shard_prepare(lib.ctx, raw.ctypes.data + off, data.nbytes, level, rank, world, C.byref(nblk),
-                                   bits.data_ptr(), bits.numel()))
+    if len(sys.argv) > 6 and sys.argv[6] == "scan":
+        # sharded split analysis: the per-byte passes on this rank's share of the tiles, 24 bytes per
+        # tile all-gathered, then the chain of boundaries on every rank
+        L.bzx_shard_scan_entries.restype = C.c_size_t
+        L.bzx_shard_scan_entries.argtypes = [C.c_size_t, C.c_uint32]
+        for f in (L.bzx_shard_scan_runs, L.bzx_shard_scan_counts):
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.bzx_shard_prepare_scanned.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
+        P = L.bzx_shard_scan_entries(data.nbytes, world)
+        tiles = torch.full((3, world, P), -7, dtype=torch.int64)          # (garbage where nobody writes)
+        lib._check(L.bzx_shard_scan_runs(lib.ctx, raw.ctypes.data + off, data.nbytes, rank, world, tiles.data_ptr()))
+        lib._check(L.bzx_ctx_sync(lib.ctx))
+        dist.all_gather_into_tensor(tiles[0].view(-1), tiles[0, rank].clone())
+        lib._check(L.bzx_shard_scan_counts(lib.ctx, raw.ctypes.data + off, data.nbytes, rank, world, tiles.data_ptr()))
+        lib._check(L.bzx_ctx_sync(lib.ctx))
+        for a in (1, 2):
+            dist.all_gather_into_tensor(tiles[a].view(-1), tiles[a, rank].clone())
+        lib._check(L.bzx_shard_prepare_scanned(lib.ctx, raw.ctypes.data + off, data.nbytes, level, rank, world,
+                                               tiles.data_ptr(), C.byref(nblk), bits.data_ptr(), bits.numel()))
+    else:
+        lib._check(L.bzx_shard_prepare(lib.ctx, raw.ctypes.data + off, data.nbytes, level, rank, world, C.byref(nblk),
+                                       bits.data_ptr(), bits.numel()))
     mine = bits.clone()
     dist.all_reduce(bits)
     # every block size is reported by exactly one rank

@@ -532,6 +532,36 @@ def test_shard_entry_points_single_rank(bzx, oracle):
     torch.cuda.synchronize()
     out = d_out[:ol.value].cpu().numpy().tobytes()
     assert nblk.value == 6 and out == bz2.compress(data, 9)
+    # the same with the sharded split analysis (bzx_shard_scan_* + bzx_shard_prepare_scanned) on
+    # run-heavy input -- runs of 1..600, a run across several blocks' worth of input -- at world 1 (the tile arrays of
+    # "all ranks" are this rank's; worlds 2 and 4, with runs across the ranks' borders: tests/test_shard_gloo.py)
+    from gen_golden import make_input
+    L.bzx_shard_scan_entries.restype = C.c_size_t
+    L.bzx_shard_scan_entries.argtypes = [C.c_size_t, C.c_uint32]
+    for f in (L.bzx_shard_scan_runs, L.bzx_shard_scan_counts):
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.bzx_shard_prepare_scanned.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p,
+                                            C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
+    data = (b"\0" * 3_000_000 + make_input(oracle, {"kind": "runs", "n": 4_000_000, "seed": 9}) + oracle.synthtext(2_000_000) +
+            b"\xee" * 700_000 + oracle.randbytes(100_000))
+    for level in (9, 2):
+        want = bz2.compress(data, level)
+        d_raw = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        P = L.bzx_shard_scan_entries(len(data), 1)
+        tiles = torch.full((3, 1, P), -5, dtype=torch.int64, device="cuda")
+        bits = torch.zeros(256, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        bzx._check(L.bzx_shard_scan_runs(bzx.ctx, d_raw.data_ptr(), len(data), 0, 1, tiles.data_ptr()))
+        bzx._check(L.bzx_shard_scan_counts(bzx.ctx, d_raw.data_ptr(), len(data), 0, 1, tiles.data_ptr()))
+        bzx._check(L.bzx_shard_prepare_scanned(bzx.ctx, d_raw.data_ptr(), len(data), level, 0, 1, tiles.data_ptr(),
+                                               C.byref(nblk), bits.data_ptr(), 256))
+        bzx._check(L.bzx_shard_emit_packed(bzx.ctx, bits.data_ptr(), d_packed.data_ptr(), cap, C.byref(pl), C.byref(ol)))
+        bzx._check(L.bzx_shard_assemble_begin(bzx.ctx, d_out.data_ptr(), cap, None))
+        bzx._check(L.bzx_shard_assemble_rank(bzx.ctx, d_packed.data_ptr(), 0, d_out.data_ptr()))
+        bzx._check(L.bzx_ctx_sync(bzx.ctx))
+        torch.cuda.synchronize()
+        assert d_out[:ol.value].cpu().numpy().tobytes() == want, level
+        assert nblk.value == len(oracle.split_rle1(data, level))
 
 
 def test_output_buffer_too_small(bzx, oracle):

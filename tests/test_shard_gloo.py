@@ -22,15 +22,19 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,kind,nbytes", [(2, "text", 230000), (2, "runs", 600000), (4, "runs", 900000),
-                                               (4, "text", 480000), (2, "dups", 420000)])
-def test_round_robin_sharding(oracle, world, kind, nbytes):
+@pytest.mark.parametrize("world,kind,nbytes,mode", [(2, "text", 230000, "whole"), (2, "runs", 600000, "whole"),
+                                                    (4, "runs", 900000, "scan"), (4, "text", 480000, "whole"),
+                                                    (2, "dups", 420000, "whole"), (2, "border", 600000, "scan"),
+                                                    (4, "border", 800000, "scan"), (2, "runs", 500000, "scan")])
+def test_round_robin_sharding(oracle, world, kind, nbytes, mode):
+    # mode "scan": the sharded split analysis (bzx_shard_scan_* + all-gathers of 24 B per tile), with runs of more than
+    # 255 bytes straddling the borders between the ranks' tile shares ("border")
     srcs = [os.path.join(ROOT, "bzip2-rust_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "bzip2-rust_amd", "csrc"))]
     if not os.path.exists(EMU_PATH) or any(os.path.getmtime(s) > os.path.getmtime(EMU_PATH) for s in srcs):
         subprocess.check_call(["bash", os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
     port = str(_free_port())
     worker = os.path.join(ROOT, "tests", "shard_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), port, str(nbytes), kind],
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), port, str(nbytes), kind, mode],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     try:
