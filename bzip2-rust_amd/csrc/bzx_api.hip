@@ -216,7 +216,9 @@ static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk, uint32_t nslab = 0)
         if ((rc = dev_alloc(ctx, ctx->slabs, &B.rec_b, (size_t)cap * BZX_MAX_N))) return rc;
         if ((rc = dev_alloc(ctx, ctx->slabs, &B.bk_list, (size_t)cap * BZX_BK_PER_BLOCK))) return rc;
         B.bk_cap = cap * BZX_BK_PER_BLOCK;
-        if ((rc = dev_alloc(ctx, ctx->slabs, &B.rk_list, (size_t)B.bk_cap))) return rc;
+        if ((rc = dev_alloc(ctx, ctx->slabs, &B.rk_list, (size_t)B.bk_cap * 2))) return rc;
+        if ((rc = dev_alloc(ctx, ctx->slabs, &B.isa2, (size_t)cap * 2 * BZX_MAX_N))) return rc;
+        B.rk_blocks = cap;
     }
     if ((rc = dev_alloc(ctx, ctx->slabs, &ctx->d_outbuf, (size_t)cap * (BZX_OUT_STRIDE / 4)))) return rc;
     ctx->cap_slabs = cap;
@@ -432,9 +434,10 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         // high-priority side stream, in sort slots of their own, beside the bucket sort of everything else.
         const bool early = ctx->n_slots >= 64;
         const uint32_t n_early = 32;
-        B.rk_slot0 = early ? n_early : 0;
-#ifdef BZX_STRESS_FEW_RANK_ARRAYS                                   // (stress builds: only eight blocks get a rank array)
-        B.rk_slot0 = ctx->n_slots - 1;
+        B.rk_slot0 = 0;
+        B.rk_blocks = ctx->cap_slabs;                               // every block in resume state gets its two rank arrays
+#ifdef BZX_STRESS_FEW_RANK_ARRAYS                                   // (stress builds: only eight blocks get rank arrays)
+        B.rk_blocks = 8;
 #endif
         B.slot_base = 0;
         B.redo_once = 0;

@@ -959,15 +959,12 @@ __device__ __attribute__((noinline)) void initial_sort(uint32_t cnt, uint32_t *r
     }
 }
 
-// Rank array (rank of every rotation, uint32[BZX_MAX_N]) of the k-th block of resume_list: the sort slots of the
-// general sorter hold eight such arrays each and are idle while the rank rounds run.  nullptr: none left.
-__device__ __forceinline__ uint32_t *rank_array(const BzxBatch &B, uint32_t k)
+// Rank arrays (rank of every rotation, uint32[BZX_MAX_N]) of the k-th block of resume_list: TWO per block -- a rank round
+// reads one and writes the other, so no rank changes under a reader (see the rank rounds).  nullptr: none.
+__device__ __forceinline__ uint32_t *rank_array(const BzxBatch &B, uint32_t k, uint32_t which)
 {
-    if (k == 0xFFFFFFFFu || B.rk_slot0 + (k >> 3) >= B.n_slots) return nullptr;      // (~0: a block with an oversized bin)
-    const BzxSortWs w = B.sort_ws[B.rk_slot0 + (k >> 3)];
-    const uint32_t q = k & 7u;
-    uint32_t *base = q < 2 ? (uint32_t *)w.u0 : q < 4 ? (uint32_t *)w.u1 : q == 4 ? w.s0 : q == 5 ? w.s1 : q == 6 ? w.isa : w.sa;
-    return base + (q < 4 && (q & 1u) ? BZX_MAX_N : 0u);
+    if (k == 0xFFFFFFFFu || k >= B.rk_blocks) return nullptr;      // (~0: a block with an oversized bin)
+    return B.isa2 + ((size_t)k * 2 + which) * BZX_MAX_N;
 }
 
 #ifndef SK_WAVES_PER_SIMD
@@ -1240,32 +1237,73 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
         tid = tid_here();
         if (fail || B.bsort_mode == 1) {
             // A bucket that gave up keeps what it has: the order so far and the group starts go to the (dead) record
-            // range of the bucket as [group start:1 @32 | rotation:20], the block is queued for the general sorter's
-            // prefix-doubling rounds, which then run on the leftover groups only.  The fill pass writes the same for
-            // the buckets of such a block that did finish (every rank its own group).
+            // range of the bucket as [group start:1 @32 | rotation:20] -- what the general sorter resumes from if the
+            // rank rounds do not finish the block -- and the block is queued for the rank rounds.  The fill pass
+            // writes the same for the buckets of such a block that did finish (every rank its own group) and enters
+            // their -- final -- ranks into both rank arrays of the block.
             uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
-            // (fill pass: the finished buckets also enter their -- final -- ranks into the block's rank array)
-            uint32_t *__restrict__ isa = fail ? nullptr : rank_array(B, uni(B.blk[b].n_selectors));
+            const uint32_t rk = fail ? 0xFFFFFFFFu : uni(B.blk[b].n_selectors);
+            uint32_t *__restrict__ isa0 = rank_array(B, rk, 0), *__restrict__ isa1 = rank_array(B, rk, 1);
 #pragma unroll
             for (uint32_t j = 0; j < BS_E; j++) {
                 const uint32_t p = j * SK_NT + tid;
                 if (p < cnt) {
                     const uint32_t rot = REC_IDX(s_x[(uint32_t)(s_w[p] & W_POS_MASK)]);
-                    // (bit 33: the rank's entry in the rank array is due -- all of them for a bucket that just gave up)
-                    sax[p] = (uint64_t)rot | ((uint64_t)fbit(p) << 32) | (fail ? 1ull << 33 : 0ull);
-                    if (isa) isa[rot] = start + p;
+                    sax[p] = (uint64_t)rot | ((uint64_t)fbit(p) << 32);
+                    if (isa0) {
+                        isa0[rot] = start + p;
+                        isa1[rot] = start + p;
+                    }
                 }
             }
-            if (fail && tid == 0) {
-                atomicMin(&B.blk[b].n_mtf, dcur / bits);
-                B.bk_list[idx].cnt = cnt | 0x80000000u;          // (the fill pass leaves this item alone)
-                B.rk_list[atomicAdd(&B.counters[BZX_CTR_RK_ITEMS], 1u)] = idx;
-                atomicAdd(&B.counters[BZX_CTR_RK_OPEN], 1u);
-                atomicAdd(&B.blk[b].n_groups, 1u);
-                if ((atomicOr(&B.blk[b].status, BZX_ST_RESUME) & BZX_ST_RESUME) == 0) {
-                    const uint32_t k = atomicAdd(&B.counters[BZX_CTR_RESUME], 1u);
-                    B.resume_list[k] = b;
-                    B.blk[b].n_selectors = k;
+            if (fail) {
+                // The rank rounds work on the TIED ranks only: they are written once more, compacted in rank order, as
+                // 4-byte entries [rotation:20 | group start:1 | rank in the bucket:11] into the bucket's range of the
+                // other record buffer (dead: records live in one buffer, their parent bin's in the other).  A round then
+                // moves 4 bytes per tied rank instead of 8 bytes per rank of the bucket.
+                uint32_t *__restrict__ cl = reinterpret_cast<uint32_t *>(B.rec_b + BZX_SLAB(B, b) * BZX_MAX_N + start);
+                uint64_t mk[BS_E];
+                lane = tid & 63u;
+                wave = tid >> 6;
+#pragma unroll
+                for (uint32_t j = 0; j < BS_E; j++) {
+                    const uint64_t f0 = s_f[j * SK_NW + wave], nx = s_f[j * SK_NW + wave + 1];
+                    mk[j] = ~(f0 & ((f0 >> 1) | (nx << 63)));
+                    if (lane == 0) s_cnt[0][j * SK_NW + wave] = (uint32_t)__popcll(mk[j]);
+                }
+                __syncthreads();
+                uint32_t total = 0, before[BS_E];
+#pragma unroll
+                for (uint32_t j = 0; j < BS_E; j++) {
+                    before[j] = 0;
+#pragma unroll
+                    for (uint32_t w = 0; w < SK_NW; w++) {
+                        const uint32_t c = s_cnt[0][j * SK_NW + w];
+                        if (w == wave) before[j] = total;
+                        total += c;
+                    }
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < BS_E; j++) {
+                    if ((mk[j] >> lane) & 1ull) {
+                        const uint32_t p = j * SK_NT + tid;
+                        const uint32_t rot = REC_IDX(s_x[(uint32_t)(s_w[p] & W_POS_MASK)]);
+                        cl[before[j] + (uint32_t)__popcll(mk[j] & ((1ull << lane) - 1ull))] = p | (fbit(p) << 11) | (rot << 12);
+                    }
+                }
+                if (tid == 0) {
+                    atomicMin(&B.blk[b].n_mtf, dcur / bits);
+                    B.bk_list[idx].cnt = cnt | 0x80000000u;          // (the fill pass leaves this item alone)
+                    const uint32_t ri = atomicAdd(&B.counters[BZX_CTR_RK_ITEMS], 1u);
+                    B.rk_list[ri] = idx;
+                    B.rk_list[B.bk_cap + ri] = total;                // tied ranks of the bucket
+                    atomicAdd(&B.counters[BZX_CTR_RK_OPEN], 1u);
+                    atomicAdd(&B.blk[b].n_groups, 1u);
+                    if ((atomicOr(&B.blk[b].status, BZX_ST_RESUME) & BZX_ST_RESUME) == 0) {
+                        const uint32_t k = atomicAdd(&B.counters[BZX_CTR_RESUME], 1u);
+                        B.resume_list[k] = b;
+                        B.blk[b].n_selectors = k;
+                    }
                 }
             }
         }
@@ -1311,19 +1349,22 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(Bzx
 __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bfill_kernel(BzxBatch B) { bsort_body(B); }
 
 // ---- rank rounds: the buckets that gave up, finished by prefix doubling ---------------------------------------
-// A bucket gives up when some of its rotations still agree after BS_ROUNDS refinement rounds (deep repeats).  Its
-// ranks and group starts were written back as [group start:1 @32 | rotation:20]; the fill pass did the same for the
-// finished buckets of the block and entered their ranks into the block's rank array.  From there on the leftover
-// groups -- all inside one bucket, so at most BS_C ranks -- are refined by the ranks of the rotations h symbols
-// ahead (h = the block's smallest give-up depth, doubling every round): exactly the refinement round of the sort
-// kernel with ISA[(rotation + h) mod n] in place of the next 50 key bits.  A round is two launches: every open
-// bucket sorts its groups by the current ranks (sort kernel), then every open bucket enters the new group heads into
-// the rank array (update kernel) -- nobody reads the array while it changes.  Any workgroup takes any bucket.
-
-// Next RK_CHUNK work items of a launch, for the whole workgroup: returns the first index and, in `open`, one bit
-// per item that is still open (after a few rounds most buckets are finished; their flags are tested 16 at a time
-// instead of one fetch each).  Dynamic rather than dealt round-robin: compute units may be busy with the general
-// sorter's early launch, and a workgroup that becomes resident late must not find a fixed share waiting for it.
+// A bucket gives up when some of its rotations still agree after BS_ROUNDS refinement rounds (deep repeats: duplicated
+// files, licence headers, tables in binaries).  Its order and group starts were written back for ALL its ranks (the
+// general sorter's fall-back) and once more, for the TIED ranks only, as a compact list of 4-byte entries; the fill
+// pass entered the ranks of the finished buckets of the block into the block's two rank arrays.  From there on the
+// leftover groups -- all inside one bucket -- are refined by the ranks of the rotations h symbols ahead (h = the
+// block's smallest give-up depth, doubling every round): the refinement round of the sort kernel with
+// ISA[(rotation + h) mod n] in place of the next 50 key bits, on the compact list.
+//   init launch : every bucket that gave up enters the group-head rank of each of its ranks into BOTH rank arrays.
+//   round r     : ONE launch.  A bucket loads its list, gathers from rank array r & 1, orders its groups, enters the
+//                 new group-head ranks into rank array (r + 1) & 1 and stores the list back without the entries that
+//                 left.  Nobody reads the array that is being written, so a reader never mixes ranks of two depths
+//                 inside one comparison.  A rank that has become the only one of its group is final: it writes its row
+//                 of the last column and its entry for the general sorter, and stays listed for ONE more round, in
+//                 which it only copies its final rank into the other array (the one that was being read when it was
+//                 settled) -- singletons of the list are exactly those.
+// Any workgroup takes any open bucket (16 per fetch; finished ones are skipped by their flags).
 #define RK_CHUNK 16
 __device__ __forceinline__ uint32_t rk_fetch_chunk(const BzxBatch &B, uint32_t n_items, uint32_t &open)
 {
@@ -1346,7 +1387,79 @@ __device__ __forceinline__ uint32_t rk_fetch_chunk(const BzxBatch &B, uint32_t n
     return s_fetch[0];
 }
 
-__global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_sort_kernel(BzxBatch B)
+// Exclusive prefix of `v` over the slots c = j * SK_NT + tid of the workgroup in slot order (one bit per slot):
+// keep[j] = bit mask of my wave's row j.  Returns the total; before[j] = kept slots before my row j.  Two barriers.
+__device__ __forceinline__ uint32_t slot_prefix(const uint64_t *keep, uint32_t nrow, uint32_t *before)
+{
+    const uint32_t lane = bzx_lane(), wave = bzx_wave();
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < BS_E; j++)
+        if (j < nrow && lane == 0) s_cnt[0][j * SK_NW + wave] = (uint32_t)__popcll(keep[j]);
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < BS_E; j++) {
+        before[j] = 0;
+        if (j < nrow) {
+#pragma unroll
+            for (uint32_t w = 0; w < SK_NW; w++) {
+                const uint32_t c = s_cnt[0][j * SK_NW + w];
+                if (w == wave) before[j] = total;
+                total += c;
+            }
+        }
+    }
+    return total;
+}
+
+__global__ __launch_bounds__(SK_NT) void bzx_brank_init_kernel(BzxBatch B)
+{
+    if (B.counters[BZX_CTR_RK_OPEN] == 0) return;
+    const uint32_t n_items = B.counters[BZX_CTR_RK_ITEMS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t chunk0 = 0, open_items = 0;
+    for (;;) {
+        if (open_items == 0) {
+            chunk0 = rk_fetch_chunk(B, n_items, open_items);
+            if (chunk0 >= n_items) break;
+            continue;
+        }
+        const uint32_t i = chunk0 + (uint32_t)__builtin_ctz(open_items);
+        open_items &= open_items - 1u;
+        const uint32_t bi = B.rk_list[i];
+        const uint32_t b = B.bk_list[bi].blk, cnt = B.bk_list[bi].cnt & 0x7fffffffu, start = B.bk_list[bi].start & 0x7fffffffu;
+        const uint32_t rk = B.blk[b].n_selectors;
+        uint32_t *__restrict__ isa0 = rank_array(B, rk, 0), *__restrict__ isa1 = rank_array(B, rk, 1);
+        if (!isa0) continue;
+        const uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
+        uint32_t rot[BS_E];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t p = j * SK_NT + tid;
+            const uint64_t v = p < cnt ? sax[p] : (1ull << 32);
+            rot[j] = (uint32_t)v & 0xFFFFFu;
+            const uint64_t m = __ballot(p >= cnt || ((v >> 32) & 1ull));
+            if (lane == 0) s_f[j * SK_NW + wave] = m;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++) {
+            const uint32_t p = j * SK_NT + tid;
+            if (p < cnt) {
+                uint32_t wi = p >> 6;
+                uint64_t w = s_f[wi] & (~0ull >> (63u - (p & 63u)));
+                while (!w) w = s_f[--wi];                          // (rank 0 of the bucket starts a group)
+                const uint32_t head = start + wi * 64 + 63u - (uint32_t)__builtin_clzll(w);
+                isa0[rot[j]] = head;
+                isa1[rot[j]] = head;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kernel(BzxBatch B)
 {
     if (B.counters[BZX_CTR_RK_OPEN] == 0) return;
     const uint32_t n_items = B.counters[BZX_CTR_RK_ITEMS];
@@ -1361,66 +1474,81 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_sort_kerne
         const uint32_t i = chunk0 + (uint32_t)__builtin_ctz(open_items);
         open_items &= open_items - 1u;
         const uint32_t bi = uni(B.rk_list[i]);
-        const uint32_t b = uni(B.bk_list[bi].blk), cnt = uni(B.bk_list[bi].cnt) & 0x7fffffffu;
-        const uint32_t start = uni(B.bk_list[bi].start) & 0x7fffffffu;
-        const uint32_t *__restrict__ isa = rank_array(B, uni(B.blk[b].n_selectors));
+        const uint32_t T = uni(B.rk_list[B.bk_cap + i]);
+        const uint32_t b = uni(B.bk_list[bi].blk), start = uni(B.bk_list[bi].start) & 0x7fffffffu;
+        const uint32_t rk = uni(B.blk[b].n_selectors);
+        const uint32_t *__restrict__ isa_r = rank_array(B, rk, B.rk_h_shift & 1u);
+        uint32_t *__restrict__ isa_w = rank_array(B, rk, (B.rk_h_shift & 1u) ^ 1u);
         const uint32_t n = uni(B.blk[b].n);
         const uint64_t h64 = (uint64_t)uni(B.blk[b].n_mtf) << B.rk_h_shift;
-        if (!isa || h64 >= n) continue;                             // (left to the general sorter: see bzx_launch_brank)
+        if (!isa_r || h64 >= n) continue;                           // (left to the general sorter: see bzx_launch_brank)
         const uint32_t h = (uint32_t)h64;
-        uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
+        uint32_t *__restrict__ cl = reinterpret_cast<uint32_t *>(B.rec_b + BZX_SLAB(B, b) * BZX_MAX_N + start);
         uint32_t tid = tid_here(), lane = tid & 63u, wave = tid >> 6;
-        uint32_t was_due = 0;                                       // bit j: the entry of row j carries a "due" mark
+        const uint32_t nrow = (T + SK_NT - 1) / SK_NT;
+        // ---- load the list: slot c holds [rotation | group start | rank p]; p stays with the slot, rotations move
+        uint32_t ent[BS_E];
+        __syncthreads();
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++) {
-            const uint32_t p = j * SK_NT + tid;
-            const uint64_t v = p < cnt ? sax[p] : (1ull << 32);
-            was_due |= (uint32_t)((v >> 33) & 1ull) << j;
-            s_x[p] = v & 0xFFFFFull;
-            s_w[p] = p;
-            const uint64_t m = __ballot(p >= cnt || ((v >> 32) & 1ull));
-            if (lane == 0) s_f[j * SK_NW + wave] = m;
+            ent[j] = 1u << 11;
+            const uint32_t c = j * SK_NT + tid;
+            if (j < nrow) {
+                if (c < T) ent[j] = cl[c];
+                s_x[c] = ent[j] >> 12;
+                LIST(0, c) = (uint16_t)(ent[j] & 2047u);
+                s_w[c] = c;
+            }
+            const uint64_t m = __ballot(c >= T || ((ent[j] >> 11) & 1u));
+            if (lane == 0) s_f[j * SK_NW + wave] = m;                // (rows beyond the list: all flagged)
         }
         if (tid == 0) {
             s_f[BS_FW] = ~0ull;
             s_rc[0][0] = s_rc[0][1] = s_rc[0][2] = s_rc[0][3] = 0;
         }
         __syncthreads();
-        // tied ranks fetch the rank of the rotation h ahead; groups above BS_TINY are listed
-        uint32_t tmask = 0, hmask = 0;
+        // ---- tied slots fetch the rank of the rotation h ahead; single slots (settled last round) copy their final rank
+        uint32_t tmask = 0, hmask = 0, zmask = 0;
         uint32_t xa[BS_E];
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++) {
-            const uint32_t p = j * SK_NT + tid;
-            const uint32_t f0 = p < cnt ? fbit(p) : 1u, f1 = p < cnt ? fbit(p + 1) : 1u;
             xa[j] = 0;
-            if (!(f0 && f1)) {
-                tmask |= 1u << j;
-                hmask |= f0 << j;
-                uint32_t x = (uint32_t)s_x[p] + h;
-                if (x >= n) x -= n;
-                xa[j] = x;
+            const uint32_t c = j * SK_NT + tid;
+            if (j < nrow && c < T) {
+                const uint32_t f0 = fbit(c), f1 = fbit(c + 1);
+                if (f0 && f1) {
+                    zmask |= 1u << j;
+                } else {
+                    tmask |= 1u << j;
+                    hmask |= f0 << j;
+                    uint32_t x = (ent[j] >> 12) + h;
+                    if (x >= n) x -= n;
+                    xa[j] = x;
+                }
             }
         }
         uint32_t g[BS_E];
 #pragma unroll
-        for (uint32_t j = 0; j < BS_E; j++) g[j] = ((tmask >> j) & 1u) ? isa[xa[j]] : 0u;
+        for (uint32_t j = 0; j < BS_E; j++) g[j] = ((tmask >> j) & 1u) ? isa_r[xa[j]] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++)
+            if ((zmask >> j) & 1u) isa_w[ent[j] >> 12] = start + (ent[j] & 2047u);
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++) {
             if ((hmask >> j) & 1u) {
-                const uint32_t p = j * SK_NT + tid;
-                uint32_t wi = p >> 6;
-                uint64_t w = (s_f[wi] >> (p & 63u)) >> 1;
+                const uint32_t c = j * SK_NT + tid;
+                uint32_t wi = c >> 6;
+                uint64_t w = (s_f[wi] >> (c & 63u)) >> 1;
                 uint32_t e;
                 if (w) {
-                    e = p + 1u + (uint32_t)__builtin_ctzll(w);
+                    e = c + 1u + (uint32_t)__builtin_ctzll(w);
                 } else {
                     do w = s_f[++wi]; while (!w);
                     e = wi * 64 + (uint32_t)__builtin_ctzll(w);
                 }
-                const uint32_t size = e - p;
-                if (size > BS_MED) s_large[atomicAdd(&s_rc[0][2], 1u)] = p | (size << 16);
-                else if (size > BS_TINY) s_med[atomicAdd(&s_rc[0][1], 1u)] = p | (size << 16);
+                const uint32_t size = e - c;
+                if (size > BS_MED) s_large[atomicAdd(&s_rc[0][2], 1u)] = c | (size << 16);
+                else if (size > BS_TINY) s_med[atomicAdd(&s_rc[0][1], 1u)] = c | (size << 16);
             }
         }
 #pragma unroll
@@ -1461,7 +1589,7 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_sort_kerne
         tid = tid_here();
         lane = tid & 63u;
         wave = tid >> 6;
-        // groups of up to BS_TINY ranks: every lane ranks its own word among its group's
+        // groups of up to BS_TINY slots: every lane ranks its own word among its group's
         uint32_t dst_[BS_E];
         uint64_t my[BS_E];
 #pragma unroll
@@ -1470,26 +1598,28 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_sort_kerne
             my[j] = 0;
             uint32_t a_ = 0, sz = 0;
             if ((tmask >> j) & 1u) {
-                const uint32_t p = j * SK_NT + tid;
+                const uint32_t c = j * SK_NT + tid;
                 uint32_t e_;
-                if (tiny_bounds(p, a_, e_) && e_ - a_ > 1) {
+                if (tiny_bounds(c, a_, e_) && e_ - a_ > 1) {
                     sz = e_ - a_;
-                    my[j] = s_w[p];
+                    my[j] = s_w[c];
                 }
             }
-            uint32_t r = 0, eq = 0;
-            for (uint32_t i2 = 0; i2 < sz; i2 += 4) {
-                uint64_t wq[4];
+            if (j < nrow) {
+                uint32_t r = 0, eq = 0;
+                for (uint32_t i2 = 0; i2 < sz; i2 += 4) {
+                    uint64_t wq[4];
 #pragma unroll
-                for (uint32_t k = 0; k < 4; k++) wq[k] = s_w[a_ + (i2 + k < sz ? i2 + k : sz - 1)];
+                    for (uint32_t k = 0; k < 4; k++) wq[k] = s_w[a_ + (i2 + k < sz ? i2 + k : sz - 1)];
 #pragma unroll
-                for (uint32_t k = 0; k < 4; k++) {
-                    const bool lt = i2 + k < sz && wq[k] < my[j];
-                    r += lt;
-                    eq += lt && ((wq[k] ^ my[j]) >> 14) == 0;
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const bool lt = i2 + k < sz && wq[k] < my[j];
+                        r += lt;
+                        eq += lt && ((wq[k] ^ my[j]) >> 14) == 0;
+                    }
                 }
+                if (sz) dst_[j] = (a_ + r) | (eq ? 0u : 0x80000000u);
             }
-            if (sz) dst_[j] = (a_ + r) | (eq ? 0u : 0x80000000u);
         }
         __syncthreads();
 #pragma unroll
@@ -1501,83 +1631,46 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_sort_kerne
             }
         }
         __syncthreads();
+        // ---- the new state of every slot that was tied: its rotation, its group's head rank into the array being
+        // written; a slot that is alone now is settled (last column, general sorter's entry, row of rotation 0)
+        const uint8_t *__restrict__ Tx = BZX_BLOCK_PTR(B, B.blk[b]);
+        uint8_t *__restrict__ L = B.bwt + BZX_SLAB(B, b) * BZX_BLK_STRIDE + start;
+        uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
+        uint64_t keep[BS_E];
+        uint32_t out[BS_E];
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++) {
-            const uint32_t p = j * SK_NT + tid;
-            // (bit 33: the rank was tied when the round began -- only those can have a new group head.  Ranks that were
-            // not tied keep their occupant and their flag: they are stored only to clear a mark left by an earlier round)
-            if (p < cnt && (((tmask | was_due) >> j) & 1u))
-                sax[p] = s_x[(uint32_t)(s_w[p] & W_POS_MASK)] | ((uint64_t)fbit(p) << 32) | ((uint64_t)((tmask >> j) & 1u) << 33);
-        }
-        __syncthreads();
-    }
-}
-
-// Every open bucket enters the head rank of each of its groups into the rank array; a bucket whose groups are all
-// single ranks is finished: its rows of the last column and the row of rotation 0 are written, and the block leaves
-// the resume state with its last open bucket.
-__global__ __launch_bounds__(SK_NT) void bzx_brank_update_kernel(BzxBatch B)
-{
-    if (B.counters[BZX_CTR_RK_OPEN] == 0) return;
-    const uint32_t n_items = B.counters[BZX_CTR_RK_ITEMS];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t chunk0 = 0, open_items = 0;
-    for (;;) {
-        if (open_items == 0) {
-            chunk0 = rk_fetch_chunk(B, n_items, open_items);
-            if (chunk0 >= n_items) break;
-            continue;
-        }
-        const uint32_t i = chunk0 + (uint32_t)__builtin_ctz(open_items);
-        open_items &= open_items - 1u;
-        const uint32_t bi = B.rk_list[i];
-        const uint32_t b = B.bk_list[bi].blk, cnt = B.bk_list[bi].cnt & 0x7fffffffu, start = B.bk_list[bi].start & 0x7fffffffu;
-        uint32_t *__restrict__ isa = rank_array(B, B.blk[b].n_selectors);
-        if (!isa) continue;
-        const uint32_t n = B.blk[b].n;
-        const uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
-        uint32_t rot[BS_E], due = 0;
-        int open = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < BS_E; j++) {
-            const uint32_t p = j * SK_NT + tid;
-            const uint64_t v = p < cnt ? sax[p] : (1ull << 32);
-            rot[j] = (uint32_t)v & 0xFFFFFu;
-            due |= (uint32_t)((v >> 33) & 1ull) << j;
-            const bool f = p >= cnt || ((v >> 32) & 1ull);
-            open |= !f;
-            const uint64_t m = __ballot(f);
-            if (lane == 0) s_f[j * SK_NW + wave] = m;
-        }
-        open = __syncthreads_or(open);
-        // ranks that were tied when the round began: new group head into the rank array
-#pragma unroll
-        for (uint32_t j = 0; j < BS_E; j++) {
-            const uint32_t p = j * SK_NT + tid;
-            if (p < cnt && ((due >> j) & 1u)) {
-                uint32_t wi = p >> 6;
-                uint64_t w = s_f[wi] & (~0ull >> (63u - (p & 63u)));
-                while (!w) w = s_f[--wi];                          // (rank 0 of the bucket starts a group)
-                isa[rot[j]] = start + wi * 64 + 63u - (uint32_t)__builtin_clzll(w);
-            }
-        }
-        // The bucket's rows of the last column, when it is finished -- and in the last launch for a bucket that is
-        // still open: it goes to the general sorter, which rewrites only the ranks that are still tied then, not the
-        // ones these rounds resolved and moved.
-        if (!open || B.rk_last) {
-            const uint8_t *__restrict__ T = BZX_BLOCK_PTR(B, B.blk[b]);
-            uint8_t *__restrict__ L = B.bwt + BZX_SLAB(B, b) * BZX_BLK_STRIDE + start;
-#pragma unroll
-            for (uint32_t j = 0; j < BS_E; j++) {
-                const uint32_t p = j * SK_NT + tid;
-                if (p < cnt) {
-                    L[p] = T[rot[j] ? rot[j] - 1 : n - 1];
-                    if (rot[j] == 0) B.blk[b].orig_ptr = start + p;
+            out[j] = 0;
+            bool kp = false;
+            const uint32_t c = j * SK_NT + tid;
+            if ((tmask >> j) & 1u) {
+                const uint32_t rot = (uint32_t)s_x[(uint32_t)(s_w[c] & W_POS_MASK)] & 0xFFFFFu;
+                const uint32_t f0 = fbit(c), f1 = fbit(c + 1), pc = LIST(0, c);
+                uint32_t wi = c >> 6;
+                uint64_t w = s_f[wi] & (~0ull >> (63u - (c & 63u)));
+                while (!w) w = s_f[--wi];                          // (slot 0 starts a group)
+                const uint32_t hc = wi * 64 + 63u - (uint32_t)__builtin_clzll(w);
+                isa_w[rot] = start + LIST(0, hc);
+                out[j] = pc | (f0 << 11) | (rot << 12);
+                kp = true;
+                if (f0 && f1) {                                    // settled
+                    L[pc] = Tx[rot ? rot - 1 : n - 1];
+                    sax[pc] = (uint64_t)rot | (1ull << 32);
+                    if (rot == 0) B.blk[b].orig_ptr = start + pc;
+                } else if (B.rk_last) {
+                    sax[pc] = (uint64_t)rot | ((uint64_t)f0 << 32);   // (still tied after the last round: general sorter)
                 }
             }
+            keep[j] = __ballot(kp);
         }
-        if (!open) {
-            if (tid == 0) {
+        uint32_t before[BS_E];
+        const uint32_t Tn = slot_prefix(keep, nrow, before);
+#pragma unroll
+        for (uint32_t j = 0; j < BS_E; j++)
+            if (j < nrow && ((keep[j] >> lane) & 1ull)) cl[before[j] + (uint32_t)__popcll(keep[j] & ((1ull << lane) - 1ull))] = out[j];
+        if (tid == 0) {
+            B.rk_list[B.bk_cap + i] = Tn;
+            if (Tn == 0) {
                 B.bk_list[bi].dbits |= 0x80000000u;
                 atomicSub(&B.counters[BZX_CTR_RK_OPEN], 1u);
                 if (atomicSub(&B.blk[b].n_groups, 1u) == 1u) atomicAnd(&B.blk[b].status, ~BZX_ST_RESUME);
@@ -1587,10 +1680,9 @@ __global__ __launch_bounds__(SK_NT) void bzx_brank_update_kernel(BzxBatch B)
     }
 }
 
-
 #ifndef RK_ROUNDS
-#define RK_ROUNDS 14                    // depths h0 .. h0 << 13: enough for give-up depths from 55 symbols on
-#endif
+#define RK_ROUNDS 15                    // depths h0 .. h0 << 13 (enough for give-up depths from 55 symbols on) + one round in
+#endif                                  // which the ranks settled last only leave their lists
 
 void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream)
 {
@@ -1602,14 +1694,13 @@ void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream)
     };
     R.rk_h_shift = 0;
     R.rk_last = 0;
-    go(bzx_brank_update_kernel);
+    go(bzx_brank_init_kernel);
     for (uint32_t r = 0; r < RK_ROUNDS; r++) {
         R.rk_h_shift = r;
-        go(bzx_brank_sort_kernel);
         R.rk_last = r + 1 == RK_ROUNDS;
-        go(bzx_brank_update_kernel);
+        go(bzx_brank_round_kernel);
     }
-    static_assert(1 + 2 * RK_ROUNDS <= BZX_N_COUNTERS - BZX_CTR_RK_FETCH, "one fetch counter per launch");
+    static_assert(1 + RK_ROUNDS <= BZX_N_COUNTERS - BZX_CTR_RK_FETCH, "one fetch counter per launch");
 }
 
 void bzx_launch_bsplit(const BzxBatch &B, uint32_t grid, hipStream_t stream)

@@ -120,7 +120,10 @@ struct BzxBatch {
                             // eight lists (few blocks: every compute unit must get work)
     uint32_t *redo_list;    // [nblk] blocks for the general sorter
     uint32_t *resume_list;  // [nblk] blocks the general sorter finishes (BZX_ST_RESUME)
-    uint32_t *rk_list;      // [bk_cap] indices into bk_list of the buckets that gave up
+    uint32_t *rk_list;      // [2 * allocated items] indices into bk_list of the buckets that gave up; [bk_cap + i]: tied ranks of
+                            // bucket rk_list[i] (entries of its compact list, see the rank rounds)
+    uint32_t *isa2;         // [blocks][2][BZX_MAX_N] two rank arrays per block in resume state (index: its place in resume_list)
+    uint32_t rk_blocks;     // blocks that get rank arrays (all; stress builds: a few)
     uint32_t rk_fetch;      // rank rounds: this launch's work-fetch counter (index into counters)
     uint32_t rk_last;       // rank rounds: this is the last update launch
     uint32_t rk_h_shift;    // rank rounds: this round compares ranks h = (give-up depth of the block) << rk_h_shift symbols ahead
