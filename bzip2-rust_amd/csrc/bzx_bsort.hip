@@ -1459,16 +1459,121 @@ __global__ __launch_bounds__(SK_NT) void bzx_brank_init_kernel(BzxBatch B)
     }
 }
 
+// One rank round of a bucket whose list has at most 64 entries, by ONE wave (slot = lane; no workgroup barrier, no
+// flag words: the group starts are a ballot).  Most buckets of real data give up over a handful of pairs, and a
+// workgroup per such bucket spent its time in barriers: four waves now take four buckets.  Same steps as the
+// workgroup form below.
+__device__ __forceinline__ void rank_round_wave(const BzxBatch &B, uint32_t i)
+{
+    const uint32_t lane = bzx_lane(), wave = bzx_wave();
+    const uint32_t bi = bzx_bcast0(B.rk_list[i]);
+    const uint32_t T = bzx_bcast0(B.rk_list[B.bk_cap + i]);
+    const uint32_t b = bzx_bcast0(B.bk_list[bi].blk), start = bzx_bcast0(B.bk_list[bi].start) & 0x7fffffffu;
+    const uint32_t rk = bzx_bcast0(B.blk[b].n_selectors);
+    const uint32_t *__restrict__ isa_r = rank_array(B, rk, B.rk_h_shift & 1u);
+    uint32_t *__restrict__ isa_w = rank_array(B, rk, (B.rk_h_shift & 1u) ^ 1u);
+    const uint32_t n = bzx_bcast0(B.blk[b].n);
+    const uint64_t h64 = (uint64_t)bzx_bcast0(B.blk[b].n_mtf) << B.rk_h_shift;
+    if (!isa_r || h64 >= n) return;
+    const uint32_t h = (uint32_t)h64;
+    uint32_t *__restrict__ cl = reinterpret_cast<uint32_t *>(B.rec_b + BZX_SLAB(B, b) * BZX_MAX_N + start);
+    uint64_t *wk = s_w + wave * 64;                         // this wave's 64 words / rotations
+    uint32_t *wr = reinterpret_cast<uint32_t *>(s_x + wave * 64);
+    const uint32_t ent = lane < T ? cl[lane] : (1u << 11);
+    const uint32_t rot = ent >> 12, pc = ent & 2047u;
+    const uint64_t F = __ballot(lane >= T || ((ent >> 11) & 1u));          // group starts (all set from T on)
+    const bool f1 = lane == 63 ? true : (F >> (lane + 1)) & 1ull;
+    const bool single = lane < T && ((F >> lane) & 1ull) && f1;
+    const bool tied = lane < T && !single;
+    if (single) isa_w[rot] = start + pc;                                   // settled last round: the other array's copy
+    uint32_t x = rot + h;
+    if (x >= n) x -= n;
+    const uint64_t key = tied ? ((uint64_t)isa_r[x] << 8) | lane : 0ull;     // (rank, then slot: a stable order)
+    const uint32_t gs = 63u - (uint32_t)__builtin_clzll((F & (~0ull >> (63u - lane))) | 1ull);
+    const uint64_t above = lane == 63 ? 0ull : F >> (lane + 1);
+    const uint32_t ge = above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : 64u;
+    lds_order();
+    wk[lane] = key;
+    lds_order();
+    uint32_t r = 0, eq = 0;
+    const uint32_t sz = tied ? ge - gs : 0u;
+    for (uint32_t k = 0; __ballot(k < sz); k++) {
+        if (k < sz) {
+            const uint64_t o = wk[gs + k];
+            const bool lt = o < key;
+            r += lt;
+            eq += lt && (o >> 8) == (key >> 8);
+        }
+    }
+    // the element of slot `lane` moves to slot gs + r; it starts a (sub)group there unless an equal rank precedes it
+    lds_order();
+    if (tied) wr[2 * (gs + r)] = rot | (eq ? 0u : 1u << 20);
+    lds_order();
+    const uint32_t nv = tied ? wr[2 * lane] : 0u;
+    const uint32_t rot_n = nv & 0xFFFFFu;
+    const uint64_t Fn = __ballot(!tied || ((F >> lane) & 1ull) || ((nv >> 20) & 1u));
+    const uint32_t hc = 63u - (uint32_t)__builtin_clzll((Fn & (~0ull >> (63u - lane))) | 1ull);
+    const uint32_t p_head = (uint32_t)__shfl((int)pc, (int)hc);
+    const bool f0n = (Fn >> lane) & 1ull, f1n = lane == 63 ? true : (Fn >> (lane + 1)) & 1ull;
+    uint32_t out = 0;
+    if (tied) {
+        isa_w[rot_n] = start + p_head;
+        out = pc | ((uint32_t)f0n << 11) | (rot_n << 12);
+        uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
+        if (f0n && f1n) {                                                  // settled
+            const uint8_t *__restrict__ Tx = BZX_BLOCK_PTR(B, B.blk[b]);
+            uint8_t *__restrict__ L = B.bwt + BZX_SLAB(B, b) * BZX_BLK_STRIDE + start;
+            L[pc] = Tx[rot_n ? rot_n - 1 : n - 1];
+            sax[pc] = (uint64_t)rot_n | (1ull << 32);
+            if (rot_n == 0) B.blk[b].orig_ptr = start + pc;
+        } else if (B.rk_last) {
+            sax[pc] = (uint64_t)rot_n | ((uint64_t)f0n << 32);
+        }
+    }
+    const uint64_t keep = __ballot(tied);
+    if (tied) cl[(uint32_t)__popcll(keep & ((1ull << lane) - 1ull))] = out;
+    if (lane == 0) {
+        const uint32_t Tn = (uint32_t)__popcll(keep);
+        B.rk_list[B.bk_cap + i] = Tn;
+        if (Tn == 0) {
+            B.bk_list[bi].dbits |= 0x80000000u;
+            atomicSub(&B.counters[BZX_CTR_RK_OPEN], 1u);
+            if (atomicSub(&B.blk[b].n_groups, 1u) == 1u) atomicAnd(&B.blk[b].status, ~BZX_ST_RESUME);
+        }
+    }
+    lds_order();
+}
+
 __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kernel(BzxBatch B)
 {
     if (B.counters[BZX_CTR_RK_OPEN] == 0) return;
     const uint32_t n_items = B.counters[BZX_CTR_RK_ITEMS];
     uint32_t chunk0 = 0, open_items = 0;
+    DIAG_T0();
     for (;;) {
         if (open_items == 0) {
             chunk0 = uni(rk_fetch_chunk(B, n_items, open_items));
             open_items = uni(open_items);
             if (chunk0 >= n_items) break;
+            if (open_items) open_items |= 0x80000000u;               // (RK_CHUNK <= 16: bit 31 marks a fresh chunk)
+            continue;
+        }
+        if (open_items & 0x80000000u) {
+            // a fresh chunk: the lists of at most 64 entries go to single waves (wave w takes the w-th, (w+4)-th, ..
+            // of them), what is left to the whole workgroup below
+            open_items &= 0x7FFFFFFFu;
+            uint32_t small = 0, seen = 0;
+            for (uint32_t m = open_items; m; m &= m - 1u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(m);
+                if (uni(B.rk_list[B.bk_cap + chunk0 + k]) <= 64u) {
+                    small |= 1u << k;
+                    if ((seen++ & (SK_NW - 1)) == (threadIdx.x >> 6)) rank_round_wave(B, chunk0 + k);
+                }
+            }
+            open_items &= ~small;
+            DIAG_COUNT(111, __builtin_popcount(small));
+            DIAG_COUNT(113 + (B.rk_h_shift < 14 ? B.rk_h_shift : 14), __builtin_popcount(small | open_items));
+            __syncthreads();
             continue;
         }
         const uint32_t i = chunk0 + (uint32_t)__builtin_ctz(open_items);
@@ -1486,6 +1591,8 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
         uint32_t *__restrict__ cl = reinterpret_cast<uint32_t *>(B.rec_b + BZX_SLAB(B, b) * BZX_MAX_N + start);
         uint32_t tid = tid_here(), lane = tid & 63u, wave = tid >> 6;
         const uint32_t nrow = (T + SK_NT - 1) / SK_NT;
+        DIAG_COUNT(110, 1);
+        DIAG_COUNT(112, T);
         // ---- load the list: slot c holds [rotation | group start | rank p]; p stays with the slot, rotations move
         uint32_t ent[BS_E];
         __syncthreads();
@@ -1678,6 +1785,7 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
         }
         __syncthreads();
     }
+    DIAG_FLUSH();
 }
 
 #ifndef RK_ROUNDS
