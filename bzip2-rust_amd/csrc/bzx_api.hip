@@ -220,6 +220,15 @@ static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk, uint32_t nslab = 0)
         if ((rc = dev_alloc(ctx, ctx->slabs, &B.isa2, (size_t)cap * 2 * BZX_MAX_N))) return rc;
         B.rk_blocks = cap;
     }
+    // MTF stage: positions of the run heads, 4 B each and one more.  With the bucket sorter they live in the block's
+    // record slab (8 B per rotation, dead once the BWT of the block is done); else in a slab of their own.
+    if (ctx->use_bsort) {
+        B.hpos = reinterpret_cast<uint32_t *>(B.rec_a);
+        B.hpos_stride = 2 * BZX_MAX_N;
+    } else {
+        if ((rc = dev_alloc(ctx, ctx->slabs, &B.hpos, (size_t)cap * (BZX_MAX_N + 64)))) return rc;
+        B.hpos_stride = BZX_MAX_N + 64;
+    }
     if ((rc = dev_alloc(ctx, ctx->slabs, &ctx->d_outbuf, (size_t)cap * (BZX_OUT_STRIDE / 4)))) return rc;
     ctx->cap_slabs = cap;
     return BZX_OK;

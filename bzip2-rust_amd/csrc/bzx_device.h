@@ -97,7 +97,9 @@ struct BzxBatch {
     const uint8_t *in;      // block slab buffer (RLE1'd bytes), block b at blk[b].in_off
     const uint8_t *raw;     // raw input (blocks on which RLE1 is the identity are read in place)
     uint8_t *bwt;           // [nblk][BZX_BLK_STRIDE]  last column L
-    uint8_t *rank;          // [nblk][BZX_BLK_STRIDE]  MTF rank of every L byte
+    uint8_t *rank;          // [nblk][BZX_BLK_STRIDE]  MTF stage: the heads of the runs of L (bytes), then their ranks
+    uint32_t *hpos;         // [nblk][hpos_stride]     MTF stage: position of every run head in L (+ the block length behind the last)
+    uint32_t hpos_stride;   // in words (the positions live in the block's record slab, which is dead after the BWT)
     uint16_t *mtfv;         // [nblk][BZX_BLK_STRIDE]  symbols (RUNA/RUNB/rank+1/EOB)
     uint32_t *freq;         // [nblk][260]             symbol histogram
     uint8_t *in_use;        // [nblk][256]

@@ -5,11 +5,14 @@
 // other ranks -> rank+1; EOB = nInUse+1 appended; histogram of the EMITTED symbols incl. EOB
 // (libbz2 counting; the reference's freqs[] is mis-indexed).
 //
-// MTF is a serial recurrence over the block.  It is cut into up to 512 chunks (one lane each):
-// the MTF list at a chunk start is "symbols by most recent occurrence before the chunk", which
-// each lane rebuilds from the per-chunk recency lists of the chunks before it.  Then every lane
-// runs the plain MTF over its own chunk with its list in LDS.  Zero-run coding is a second,
-// fully parallel sweep over the rank bytes (max-scan for run starts, sum-scan for offsets).
+// MTF is a serial recurrence over the block -- but only the HEADS of its runs take part in it: a byte equal to its
+// predecessor has rank 0 and leaves the list as it is (the last column of text is mostly runs: 45 % of its bytes are
+// heads).  So the block is first compacted to its run heads (byte + position, one parallel pass that also marks the
+// bytes in use); the recurrence runs over the heads, cut into up to 1024 chunks (one lane each): the MTF list at a
+// chunk start is "symbols by most recent occurrence before the chunk", which each lane rebuilds from the per-chunk
+// recency lists of the chunks before it; then every lane runs the plain MTF over its own heads.  Zero-run coding is a
+// parallel pass over the heads: a head emits its rank (+1) and the RUNA/RUNB digits of the zeros behind it, whose
+// number is the distance to the next head (sum-scan for offsets).
 #include <hip/hip_runtime.h>
 #include "bzx_device.h"
 #include "bzx_wg.h"
@@ -18,8 +21,11 @@
 #define MTF_LIST_BYTES (72 * 1024)
 #define MTF_E 16
 
-__shared__ __attribute__((aligned(16))) uint8_t m_rec[MTF_LIST_BYTES];    // per-chunk recency lists (most recent first)
-__shared__ __attribute__((aligned(16))) uint8_t m_list[MTF_LIST_BYTES + 32];   // per-chunk working MTF lists (+ read slack of the 4-word walk)
+// one pool: per-chunk recency lists (most recent first), then the per-chunk working MTF lists (+ read slack of the
+// 4-word walk); the zero-run pass parks a tile's symbols in all of it (up to ~63,000 of them: 8,192 heads of runs)
+__shared__ __attribute__((aligned(16))) uint8_t m_pool[2 * MTF_LIST_BYTES + 32];
+#define m_rec m_pool
+#define m_list (m_pool + MTF_LIST_BYTES)
 __shared__ uint16_t m_reccnt[MTF_NT];
 #define MTF_GROUP 32                                   // chunks per group of the two-level start-list walk
 __shared__ uint8_t m_super[(MTF_NT / MTF_GROUP) * 264];   // recency list of every group of 32 chunks
@@ -71,7 +77,7 @@ template <int NW> struct SeenSet {
 // with the zero-byte trick, then every word is either shifted by one entry (words before the hit), patched
 // (the hit word) or left alone -- no LDS traffic and no divergence inside the loop.
 template <int NWORD>
-__device__ __forceinline__ void mtf_ranks_regs(const uint8_t *__restrict__ L, uint8_t *__restrict__ R, uint32_t c_lo,
+__device__ __forceinline__ void mtf_ranks_regs(const uint8_t *L, uint8_t *R, uint32_t c_lo,
                                                uint32_t c_hi, const uint64_t *lst64, const uint8_t *seq)
 {
     const uint64_t ones = 0x0101010101010101ull, highs = 0x8080808080808080ull;
@@ -236,27 +242,67 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
 
         const uint32_t n = B.blk[b].n;
         const uint8_t *__restrict__ L = B.bwt + BZX_SLAB(B, b) * BZX_BLK_STRIDE;
-        uint8_t *__restrict__ R = B.rank + BZX_SLAB(B, b) * BZX_BLK_STRIDE;
+        uint8_t *H = B.rank + BZX_SLAB(B, b) * BZX_BLK_STRIDE;          // run heads (bytes), then their ranks, in place
+        uint32_t *__restrict__ P = B.hpos + BZX_SLAB(B, b) * (size_t)B.hpos_stride;     // position of every head; P[nh] = n
         uint16_t *__restrict__ V = B.mtfv + BZX_SLAB(B, b) * BZX_BLK_STRIDE;
 
         if (B.dbg && tid == 0) t_last = wall_clock64();
-        // ---- 1. bytes in use -> dense ids (rle2_mtf.rs:26-45)
+        // ---- 1. bytes in use (rle2_mtf.rs:26-45) and the run heads: byte i is a head unless it equals byte i-1.  A tile
+        // of 16 bytes per lane; the heads of a tile are parked in LDS (bytes and positions) and leave by consecutive lanes.
         if (tid < 256) m_inuse[tid] = 0;
         for (uint32_t i = tid; i < BZX_MAX_ALPHA + 2; i += MTF_NT) m_freq[i] = 0;
+        if (tid == 0) m_bcast[1] = 0;
         __syncthreads();
         {
-            const uint32_t n16 = n & ~15u;
-            for (uint32_t i = tid * 16; i < n16; i += MTF_NT * 16) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(L + i);
+            uint8_t *sth = m_rec;                                       // [MTF_NT * 16] heads of the tile
+            uint32_t *stp = reinterpret_cast<uint32_t *>(m_list);       // [MTF_NT * 16] their positions
+            static_assert(MTF_LIST_BYTES >= MTF_NT * MTF_E * 4, "tile staging");
+            uint32_t done = 0;                                          // heads of the earlier tiles
+            for (uint32_t t0 = 0; t0 < n; t0 += MTF_NT * MTF_E) {
+                const uint32_t i0 = t0 + tid * MTF_E;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                uint32_t prev = 0x100;                                  // (no byte: position 0 is a head)
+                if (i0 < n) {
+                    v = *reinterpret_cast<const uint4 *>(L + i0);       // bytes past n are ignored below
+                    if (i0) prev = L[i0 - 1];
+                }
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                uint32_t hm = 0;
 #pragma unroll
-                for (int q = 0; q < 4; q++)
+                for (int k = 0; k < MTF_E; k++) {
+                    const uint32_t c = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+                    if (i0 + k < n) {
+                        m_inuse[c] = 1;
+                        hm |= (uint32_t)(c != prev) << k;
+                    }
+                    prev = c;
+                }
+                uint32_t tot;
+                const uint32_t ex = bzx_block_excl_sum_lds<MTF_NT>((uint32_t)__popc(hm), m_scratch, tot);
+                uint32_t o = ex;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) m_inuse[(w[q] >> (8 * k)) & 255u] = 1;
+                for (int k = 0; k < MTF_E; k++) {
+                    if ((hm >> k) & 1u) {
+                        sth[o] = (uint8_t)((w[k >> 2] >> (8 * (k & 3))) & 255u);
+                        stp[o] = i0 + k;
+                        o++;
+                    }
+                }
+                bzx_lds_barrier();
+                for (uint32_t q = tid; q < tot; q += MTF_NT) {
+                    H[done + q] = sth[q];
+                    P[done + q] = stp[q];
+                }
+                done += tot;
+                bzx_lds_barrier();
             }
-            for (uint32_t i = n16 + tid; i < n; i += MTF_NT) m_inuse[L[i]] = 1;
+            if (tid == 0) {
+                P[done] = n;
+                m_bcast[1] = done;
+            }
         }
         __syncthreads();
+        const uint32_t nh = m_bcast[1];                                 // run heads (>= 1)
         uint32_t n_in_use;
         {
             const uint32_t flag = tid < 256 ? m_inuse[tid] : 0u;
@@ -266,26 +312,26 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
                 B.in_use[BZX_SLAB(B, b) * 256 + tid] = (uint8_t)flag;
             }
         }
-        __syncthreads();
+        __syncthreads();                                                // (also: the heads written above are visible)
 
         MTF_STAMP(32);
-        // ---- 2. chunking: at most 512 chunks; a list is stride64 (odd) 8-byte words per chunk, lists fit 72 KiB
+        // ---- 2. chunking of the heads: a list is stride64 (odd) 8-byte words per chunk, lists fit 72 KiB
         const uint32_t stride64 = ((n_in_use + 7) / 8) | 1u;      // odd word stride: conflict-free 64-bit LDS access
         const uint32_t stride = stride64 * 8;
         uint32_t nch = MTF_LIST_BYTES / stride;
         if (nch > MTF_NT) nch = MTF_NT;
-        uint32_t csz = (n + nch - 1) / nch;
+        uint32_t csz = (nh + nch - 1) / nch;
         csz = (csz + 15u) & ~15u;
-        const uint32_t nch_used = (n + csz - 1) / csz;
+        const uint32_t nch_used = (nh + csz - 1) / csz;
         const uint32_t c_lo = tid * csz;
-        const uint32_t c_hi = (c_lo + csz < n) ? c_lo + csz : n;
+        const uint32_t c_hi = (c_lo + csz < nh) ? c_lo + csz : nh;
         const bool have_chunk = tid < nch_used;
 
         // ---- 3. recency list of my chunk: distinct symbols by last occurrence, most recent first
         if (have_chunk) {
-            if (n_in_use <= 64) mtf_recency<1>(L, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid]);
-            else if (n_in_use <= 128) mtf_recency<2>(L, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid]);
-            else mtf_recency<4>(L, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid]);
+            if (n_in_use <= 64) mtf_recency<1>(H, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid]);
+            else if (n_in_use <= 128) mtf_recency<2>(H, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid]);
+            else mtf_recency<4>(H, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid]);
         }
         __syncthreads();
         MTF_STAMP(33);
@@ -297,23 +343,23 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         __syncthreads();
         MTF_STAMP(34);
 
-        // ---- 5. plain MTF over my chunk (rle2_mtf.rs:61-138), rank bytes to HBM.
+        // ---- 5. plain MTF over my heads (rle2_mtf.rs:61-138); a head's rank replaces its byte.
         // The first 8 list entries live in a register (byte 0 = front); deeper entries in LDS as 8-byte words,
         // searched and shifted one word at a time.
         if (have_chunk && n_in_use <= 32) {
             const uint64_t *lst64 = reinterpret_cast<const uint64_t *>(m_list + tid * stride);
-            if (n_in_use <= 8) mtf_ranks_regs<1>(L, R, c_lo, c_hi, lst64, m_seq);
-            else if (n_in_use <= 16) mtf_ranks_regs<2>(L, R, c_lo, c_hi, lst64, m_seq);
-            else if (n_in_use <= 24) mtf_ranks_regs<3>(L, R, c_lo, c_hi, lst64, m_seq);
-            else mtf_ranks_regs<4>(L, R, c_lo, c_hi, lst64, m_seq);
+            if (n_in_use <= 8) mtf_ranks_regs<1>(H, H, c_lo, c_hi, lst64, m_seq);
+            else if (n_in_use <= 16) mtf_ranks_regs<2>(H, H, c_lo, c_hi, lst64, m_seq);
+            else if (n_in_use <= 24) mtf_ranks_regs<3>(H, H, c_lo, c_hi, lst64, m_seq);
+            else mtf_ranks_regs<4>(H, H, c_lo, c_hi, lst64, m_seq);
         } else if (have_chunk) {
             uint64_t *lst64 = reinterpret_cast<uint64_t *>(m_list + tid * stride);
             uint64_t w = lst64[0];
             const uint64_t ones = 0x0101010101010101ull, highs = 0x8080808080808080ull;
-            uint4 nxt = *reinterpret_cast<const uint4 *>(L + c_lo);
+            uint4 nxt = *reinterpret_cast<const uint4 *>(H + c_lo);
             for (uint32_t i0 = c_lo; i0 < c_hi; i0 += 16) {
                 const uint4 v = nxt;
-                if (i0 + 16 < c_hi) nxt = *reinterpret_cast<const uint4 *>(L + i0 + 16);
+                if (i0 + 16 < c_hi) nxt = *reinterpret_cast<const uint4 *>(H + i0 + 16);
                 const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
                 uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -373,83 +419,71 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
                         }
                     }
                 }
-                *reinterpret_cast<uint4 *>(R + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<uint4 *>(H + i0) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         }
         __syncthreads();
         MTF_STAMP(35);
-        // ---- 6. zero-run coding + symbol emission + histogram (rle2_mtf.rs:63-172)
-        if (tid == 0) {
-            m_bcast[1] = 0;
-            m_bcast[2] = 0;
-        }
+        // ---- 6. zero-run coding + symbol emission + histogram (rle2_mtf.rs:63-172), one head at a time: head k emits
+        // rank + 1 (every head but possibly the first has a nonzero rank) and then the RUNA/RUNB digits of the zeros
+        // that follow it up to the next head: P[k+1] - P[k] - 1 of them (one more for a first head of rank 0).
+        if (tid == 0) m_bcast[2] = 0;
         __syncthreads();
         uint32_t hot0 = 0, hot1 = 0, hot2 = 0;      // RUNA, RUNB and symbol 2 (rank 1) counted in registers
         // The symbols of a tile are collected in LDS (the recency lists are dead by now) and written to V as aligned
         // 4-byte pairs by consecutive lanes, instead of one 2-byte store per symbol.  When the count so far is odd,
         // the last symbol waits in stg[0] for the next tile: pend = carry_out & 1.
-        uint16_t *stg = reinterpret_cast<uint16_t *>(m_rec);
-        // software pipeline: the rank bytes of the next tile are loaded while this one is scanned and emitted;
-        // the barriers inside the loop order LDS only
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (tid * MTF_E < n) nxt = *reinterpret_cast<const uint4 *>(R + tid * MTF_E);   // bytes past n are ignored below
-        for (uint32_t t0 = 0; t0 < n; t0 += MTF_NT * MTF_E) {
-            const uint32_t i0 = t0 + tid * MTF_E;
-            const uint32_t carry_p1 = m_bcast[1], carry_out = m_bcast[2];
-            const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
-            {
-                const uint32_t i1 = i0 + MTF_NT * MTF_E;
-                nxt = make_uint4(0, 0, 0, 0);
-                if (i1 < n) nxt = *reinterpret_cast<const uint4 *>(R + i1);
-            }
-            // last nonzero position (+1) inside my 16 bytes
-            uint32_t my_p1 = 0;
+        uint16_t *stg = reinterpret_cast<uint16_t *>(m_pool);
+        constexpr uint32_t HE = 8;                  // heads per lane and tile
+        // (a tile's symbols fit: H heads of runs l_i emit H + sum floor(log2 l_i) symbols, sum l_i <= 900,000; for H = 8,192
+        // that is at most 8,192 * 7 + 5,875 = 63,219 symbols of 2 bytes)
+        static_assert(2 * MTF_LIST_BYTES >= 2 * 64000, "symbol staging of a tile");
+        for (uint32_t t0 = 0; t0 < nh; t0 += MTF_NT * HE) {
+            const uint32_t k0 = t0 + tid * HE;
+            const uint32_t carry_out = m_bcast[2];
+            uint32_t rk[HE], zr[HE];
+            uint32_t my_cnt = 0;
+            if (k0 < nh) {
+                uint2 rv;
+                __builtin_memcpy(&rv, H + k0, 8);                       // (8-byte aligned: k0 is a multiple of 8)
+                uint32_t pp[HE + 1];
 #pragma unroll
-            for (int k = 0; k < MTF_E; k++) {
-                const uint32_t i = i0 + k;
-                const uint32_t r = (w[k >> 2] >> (8 * (k & 3))) & 255u;
-                if (i < n && r != 0) my_p1 = i + 1;
-            }
-            uint32_t dummy_s, dummy_t, p1_excl, p1_total;
-            bzx_block_scan_sum_max_lds<MTF_NT>(0u, my_p1, m_scratch, dummy_s, dummy_t, p1_excl, p1_total);
-            const uint32_t p1_in = p1_excl ? p1_excl : carry_p1;
-            // count my output symbols
-            uint32_t p1 = p1_in, my_cnt = 0;
+                for (uint32_t k = 0; k <= HE; k++) pp[k] = k0 + k <= nh ? P[k0 + k] : n;
 #pragma unroll
-            for (int k = 0; k < MTF_E; k++) {
-                const uint32_t i = i0 + k;
-                const uint32_t r = (w[k >> 2] >> (8 * (k & 3))) & 255u;
-                if (i < n && r != 0) {
-                    const uint32_t zr = i - p1;
-                    my_cnt += 1u + (zr ? 31u - (uint32_t)__clz(zr + 1u) : 0u);
-                    p1 = i + 1;
+                for (uint32_t k = 0; k < HE; k++) {
+                    rk[k] = ((k < 4 ? rv.x : rv.y) >> (8 * (k & 3))) & 255u;
+                    zr[k] = 0;
+                    if (k0 + k < nh) {
+                        zr[k] = pp[k + 1] - pp[k] - 1u + ((k0 + k == 0 && rk[k] == 0) ? 1u : 0u);
+                        my_cnt += (rk[k] ? 1u : 0u) + (zr[k] ? 31u - (uint32_t)__clz(zr[k] + 1u) : 0u);
+                    } else {
+                        rk[k] = 0;
+                    }
                 }
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < HE; k++) rk[k] = zr[k] = 0;
             }
             uint32_t cnt_total;
             const uint32_t cnt_excl = bzx_block_excl_sum_lds<MTF_NT>(my_cnt, m_scratch, cnt_total);
-            // emit
             const uint32_t pend = carry_out & 1u;
             uint32_t o = pend + cnt_excl;               // index in stg; V index = carry_out - pend + index
-            p1 = p1_in;
 #pragma unroll
-            for (int k = 0; k < MTF_E; k++) {
-                const uint32_t i = i0 + k;
-                const uint32_t r = (w[k >> 2] >> (8 * (k & 3))) & 255u;
-                if (i < n && r != 0) {
-                    uint32_t zr = i - p1;
-                    if (zr) {
-                        zr--;
-                        for (;;) {
-                            const uint32_t sym = zr & 1u;
-                            stg[o++] = (uint16_t)sym;
-                            if (sym) hot1++; else hot0++;
-                            if (zr < 2) break;
-                            zr = (zr - 2) >> 1;
-                        }
+            for (uint32_t k = 0; k < HE; k++) {
+                if (rk[k]) {
+                    stg[o++] = (uint16_t)(rk[k] + 1);
+                    if (rk[k] == 1) hot2++; else atomicAdd(&m_freq[rk[k] + 1], 1u);
+                }
+                uint32_t z = zr[k];
+                if (z) {
+                    z--;
+                    for (;;) {
+                        const uint32_t sym = z & 1u;
+                        stg[o++] = (uint16_t)sym;
+                        if (sym) hot1++; else hot0++;
+                        if (z < 2) break;
+                        z = (z - 2) >> 1;
                     }
-                    stg[o++] = (uint16_t)(r + 1);
-                    if (r == 1) hot2++; else atomicAdd(&m_freq[r + 1], 1u);
-                    p1 = i + 1;
                 }
             }
             bzx_lds_barrier();
@@ -459,35 +493,21 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
                 const uint32_t *src = reinterpret_cast<const uint32_t *>(stg);
                 for (uint32_t q = tid; q < (total >> 1); q += MTF_NT) dst[q] = src[q];
                 const uint16_t left = stg[total ? total - 1 : 0];
-                if (tid == 0) {
-                    if (p1_total) m_bcast[1] = p1_total;
-                    m_bcast[2] = carry_out + cnt_total;
-                }
+                if (tid == 0) m_bcast[2] = carry_out + cnt_total;
                 bzx_lds_barrier();
                 if (tid == 0 && (total & 1u)) stg[0] = left;
             }
         }
         __syncthreads();
-        if (tid == 0 && (m_bcast[2] & 1u)) V[m_bcast[2] - 1] = stg[0];      // the symbol still waiting for a partner
         if (hot0) atomicAdd(&m_freq[0], hot0);
         if (hot1) atomicAdd(&m_freq[1], hot1);
         if (hot2) atomicAdd(&m_freq[2], hot2);
         __syncthreads();
         MTF_STAMP(36);
-        // trailing zero run + EOB
+        // EOB (the zeros behind the last head were its own)
         if (tid == 0) {
             uint32_t o = m_bcast[2];
-            uint32_t zr = n - m_bcast[1];
-            if (zr) {
-                zr--;
-                for (;;) {
-                    const uint32_t sym = zr & 1u;
-                    V[o++] = (uint16_t)sym;
-                    m_freq[sym]++;
-                    if (zr < 2) break;
-                    zr = (zr - 2) >> 1;
-                }
-            }
+            if (o & 1u) V[o - 1] = stg[0];                              // the symbol still waiting for a partner
             const uint32_t eob = n_in_use + 1;
             V[o++] = (uint16_t)eob;
             m_freq[eob]++;
