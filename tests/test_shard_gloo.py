@@ -22,10 +22,9 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,kind,nbytes,mode", [(2, "text", 230000, "whole"), (2, "runs", 600000, "whole"),
-                                                    (4, "runs", 900000, "scan"), (4, "text", 480000, "whole"),
-                                                    (2, "dups", 420000, "whole"), (2, "border", 600000, "scan"),
-                                                    (4, "border", 800000, "scan"), (2, "runs", 500000, "scan")])
+@pytest.mark.parametrize("world,kind,nbytes,mode", [(2, "text", 230000, "whole"), (4, "runs", 600000, "whole"),
+                                                    (4, "runs", 700000, "scan"), (2, "dups", 420000, "whole"),
+                                                    (2, "border", 450000, "scan"), (4, "border", 600000, "scan")])
 def test_round_robin_sharding(oracle, world, kind, nbytes, mode):
     # mode "scan": the sharded split analysis (bzx_shard_scan_* + all-gathers of 24 B per tile), with runs of more than
     # 255 bytes straddling the borders between the ranks' tile shares ("border")
