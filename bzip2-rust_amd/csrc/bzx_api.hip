@@ -621,7 +621,7 @@ static void collect_stage_times(bzx_ctx *ctx)
     ctx->stats.n_redo = 0;
     ctx->stats.n_buckets = 0;
     ctx->stats.ms_bwt_split = ctx->stats.ms_bwt_sort = ctx->stats.ms_bwt_general = ctx->stats.ms_bwt_rank = 0.f;
-    ctx->stats.n_open_buckets = ctx->stats.n_open_left = ctx->stats.n_resume_left = ctx->stats.n_from_scratch = 0;
+    ctx->stats.n_open_buckets = ctx->stats.n_open_left = ctx->stats.n_resume_left = ctx->stats.n_from_scratch = ctx->stats.n_unsorted = 0;
     if (ctx->bsort_used) {
         ctx->stats.n_redo = ctx->h_counters[BZX_CTR_REDO] + ctx->h_counters[BZX_CTR_RESUME];
         ctx->stats.n_buckets = 0;
@@ -634,6 +634,7 @@ static void collect_stage_times(bzx_ctx *ctx)
         ctx->stats.n_open_left = ctx->h_counters[BZX_CTR_RK_OPEN];
         ctx->stats.n_resume_left = ctx->h_counters[BZX_CTR_RESUME_LEFT];
         ctx->stats.n_from_scratch = ctx->h_counters[BZX_CTR_REDO];
+        ctx->stats.n_unsorted = ctx->h_counters[BZX_CTR_STAT0 + 15];
 
     }
     ctx->stats.bwt_launches = ctx->bwt_launches;

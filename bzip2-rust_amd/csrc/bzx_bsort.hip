@@ -59,9 +59,6 @@
 #ifndef BS_KEYBITS
 #define BS_KEYBITS 32                   // leading bits of the 32-bit record key sorted by the initial LSD passes (a multiple of 8)
 #endif
-#ifndef BS_OPTIMISTIC
-#define BS_OPTIMISTIC 1                 // initial sort by returning LDS atomics, checked (0: ballot-ranked passes only)
-#endif
 #define BS_TINY 64                      // groups up to this size are ranked by counting
 #define BS_MED 512                      // ... up to this size by one wave
 #define REC_IDX(r) ((uint32_t)((r) >> 12) & 0xFFFFFu)
@@ -735,9 +732,8 @@ __device__ __attribute__((noinline)) void wg_radix_sort_opt(uint32_t cnt, int lo
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++) {
             const uint32_t e = wave * chunk + j * 64 + lane;
-            old[j] = 0;
-            if (j < rows && e < cnt) old[j] = atomicAdd(&wc[(uint32_t)(v[j] >> shift) & (SK_ND - 1)], 1u);
-            lds_order();                                    // rows in order: a wave's LDS instructions execute in issue order
+            // (rows in order: a wave's LDS instructions execute in issue order)
+            old[j] = bzx_lds_ticket(&wc[(uint32_t)(v[j] >> shift) & (SK_ND - 1)], j < rows && e < cnt);
         }
         __syncthreads();
         {
@@ -918,32 +914,27 @@ __device__ __attribute__((noinline)) void list_tied(uint32_t n, uint32_t from, u
 }
 
 // Initial sort of the bucket's records s_x[0 .. cnt) by their 32 key bits; afterwards rank p holds record p
-// (s_w[p] = p) and the group-start flags say where the key differs from the predecessor's.  The optimistic passes
-// run first (see wg_radix_sort_opt); an inversion among the sorted keys -- never seen -- sends the bucket through the
-// ballot-ranked passes, whose order needs no checking.  *resorted counts such buckets.
-__device__ __attribute__((noinline)) void initial_sort(uint32_t cnt, uint32_t *resorted)
+// (s_w[p] = p), the group-start flags say where the key differs from the predecessor's and list 0 holds the tied
+// ranks.  The passes are the optimistic ones (see wg_radix_sort_opt); false: an inversion among the sorted keys --
+// never seen -- and the caller hands the block to the general sorter.
+__device__ __forceinline__ bool initial_sort(uint32_t cnt)
 {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = tid_here(), lane = tid & 63u, wave = tid >> 6;
     uint64_t fm[BS_E];                               // group-start flags of my wave's row j (wave-uniform)
-    for (int attempt = 0;; attempt++) {
-        if (attempt == 0 && BS_OPTIMISTIC) wg_radix_sort_opt(cnt, 64 - BS_KEYBITS, 64);
-        else wg_radix_sort<0>(0, cnt, 64 - BS_KEYBITS, 64);
-        int bad = 0;
+    wg_radix_sort_opt(cnt, 64 - BS_KEYBITS, 64);
+    int bad = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < BS_E; j++) {
-            const uint32_t p = j * SK_NT + tid;
-            s_w[p] = p;
-            const uint64_t kp = s_x[p] >> (64 - BS_KEYBITS), kq = p ? s_x[p - 1] >> (64 - BS_KEYBITS) : 0ull;
-            const bool f = p >= cnt || p == 0 || kp != kq;
-            bad |= p < cnt && p > 0 && kp < kq;
-            fm[j] = __ballot(f);
-            if (lane == 0) s_f[j * SK_NW + wave] = fm[j];
-        }
-        if (tid == 0) s_f[BS_FW] = ~0ull;
-        bad = __syncthreads_or(bad);
-        if (!bad || attempt) break;
-        if (tid == 0) atomicAdd(resorted, 1u);
+    for (uint32_t j = 0; j < BS_E; j++) {
+        const uint32_t p = j * SK_NT + tid;
+        s_w[p] = p;
+        const uint64_t kp = s_x[p] >> (64 - BS_KEYBITS), kq = p ? s_x[p - 1] >> (64 - BS_KEYBITS) : 0ull;
+        const bool f = p >= cnt || p == 0 || kp != kq;
+        bad |= p < cnt && p > 0 && kp < kq;
+        fm[j] = __ballot(f);
+        if (lane == 0) s_f[j * SK_NW + wave] = fm[j];
     }
+    if (tid == 0) s_f[BS_FW] = ~0ull;
+    if (__syncthreads_or(bad)) return false;
     // The list of tied ranks (see list_tied), straight from the flag words: rank p is tied unless a group starts at p
     // and at p + 1; the flag after a row's last rank is bit 0 of the next flag word (ranks from cnt on are all flagged).
 #pragma unroll
@@ -957,6 +948,7 @@ __device__ __attribute__((noinline)) void initial_sort(uint32_t cnt, uint32_t *r
             if ((mk >> lane) & 1ull) LIST(0, base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))) = (uint16_t)(j * SK_NT + tid);
         }
     }
+    return true;
 }
 
 // Rank arrays (rank of every rotation, uint32[BZX_MAX_N]) of the k-th block of resume_list: TWO per block -- a rank round
@@ -1059,7 +1051,21 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
         }
         if (tid == 0) s_rc[0][0] = s_rc[0][1] = s_rc[0][2] = s_rc[0][3] = s_m[0] = s_m[1] = 0;
         DIAG_STAMP(65);
-        initial_sort(cnt, &B.counters[BZX_CTR_STAT0 + 15]);     // (its first barrier also publishes s_x)
+        if (!initial_sort(cnt)) {                               // (its first barrier also publishes s_x)
+            // the optimistic passes did not deliver a sorted bucket (see wg_radix_sort_opt): the whole block goes to
+            // the general sorter, which needs nothing from here
+            if (tid == 0) {
+                atomicAdd(&B.counters[BZX_CTR_STAT0 + 15], 1u);
+                block_redo(B, b);
+            }
+            PREFETCH_NEXT();
+            __syncthreads();
+            it = nit;
+            nit = uni(nit2);
+            n_cur = uni(n_nx);
+            st_cur = uni(st_nx);
+            continue;
+        }
         DIAG_STAMP(67);
 
         // ---- refinement rounds over the LIST of tied ranks.  After 47 key bits most ranks are alone in their group (83 %

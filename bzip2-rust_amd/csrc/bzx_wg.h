@@ -39,6 +39,33 @@
 // derived from it from being hoisted out of the loop, where dozens of such values would be spilled and reloaded from
 // scratch (global memory) inside the hot loops.
 // bzx_drain_stores(): all of this lane's global stores have landed (before the wave reads them back).
+// bzx_lds_ticket(): one returning LDS add of 1 per valid lane.  On the device the lanes of a wave instruction that name
+// the same counter are served in lane order (observed, not promised: the sort kernel checks what it builds on it); the
+// emulator runs lanes in whatever order its scheduler resumes them, so it hands out the tickets by lane number itself.
+#ifdef BZX_HIP_EMU
+__device__ inline uint32_t bzx_lds_ticket(uint32_t *ctr, bool valid)
+{
+    static uintptr_t who[16][64];                   // (the emulator runs one workgroup at a time)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uintptr_t me = valid ? (uintptr_t)ctr : 0;
+    who[wave][lane] = me;
+    hipemu::wave_sync();
+    uint32_t before = 0, same = 0;
+    for (uint32_t l = 0; l < 64; l++) {
+        if (valid && who[wave][l] == me) {
+            same++;
+            if (l < lane) before++;
+        }
+    }
+    const uint32_t base = valid ? *ctr : 0u;
+    hipemu::wave_sync();
+    if (valid && before == 0) *ctr = base + same;
+    hipemu::wave_sync();
+    return base + before;
+}
+#else
+__device__ __forceinline__ uint32_t bzx_lds_ticket(uint32_t *ctr, bool valid) { return valid ? atomicAdd(ctr, 1u) : 0u; }
+#endif
 #ifdef BZX_HIP_EMU
 #define lds_order() hipemu::wave_sync()
 __device__ __forceinline__ uint32_t bzx_uni(uint32_t v) { return v; }

@@ -218,6 +218,7 @@ typedef struct {
     uint32_t n_resume_left;       /* blocks the general sorter had to finish */
     float ms_bwt_rank;            /* part of ms_bwt_general: rank rounds over the open buckets */
     uint32_t n_from_scratch;      /* blocks the split kernel refused (sorted from scratch by the general sorter) */
+    uint32_t n_unsorted;          /* buckets whose optimistic initial sort failed its check (their blocks went to the general sorter): 0 */
 } bzx_stats;
 int bzx_get_stats(const bzx_ctx *ctx, bzx_stats *out);
 

@@ -22,7 +22,7 @@ class BzxStats(C.Structure):
                 ("bwt_launches", C.c_uint32), ("n_redo", C.c_uint32), ("n_buckets", C.c_uint32),
                 ("ms_bwt_split", C.c_float), ("ms_bwt_sort", C.c_float), ("ms_bwt_general", C.c_float),
                 ("n_open_buckets", C.c_uint32), ("n_open_left", C.c_uint32), ("n_resume_left", C.c_uint32),
-                ("ms_bwt_rank", C.c_float), ("n_from_scratch", C.c_uint32)]
+                ("ms_bwt_rank", C.c_float), ("n_from_scratch", C.c_uint32), ("n_unsorted", C.c_uint32)]
 
 
 class BzxBlockInfo(C.Structure):

@@ -116,7 +116,9 @@ def test_emu_leftover_groups_paths(emu, oracle):
     assert emu.compress_buffer(dup, 9) == bz2.compress(dup, 9)
     st = emu.stats()
     assert st.n_open_buckets > 0 and st.n_open_left == 0 and st.n_resume_left == 0 and st.n_from_scratch == 0
+    assert st.n_unsorted == 0          # the optimistic initial sort's check never failed (bzx_bsort.hip, wg_radix_sort_opt)
     runs = (b"ab" * 700 + b"c") * 6 + b"d"
+
     assert emu.compress_buffer(runs, 9) == bz2.compress(runs, 9)
     st = emu.stats()
     assert st.n_resume_left == 1 and st.n_from_scratch == 0

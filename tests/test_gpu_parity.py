@@ -128,6 +128,7 @@ def test_stream_golden(bzx, oracle, name):
     out = bzx.compress_buffer(data, g["level"])
     assert len(out) == g["bz2_len"]
     assert hashlib.sha256(out).hexdigest() == g["bz2_sha256"]
+    assert bzx.stats().n_unsorted == 0      # no bucket's optimistic initial sort failed its check (bzx_bsort.hip)
     if len(data) <= (8 << 20):
         assert out == bz2.compress(data, g["level"])
     else:
@@ -383,6 +384,7 @@ def test_leftover_groups_paths(bzx, oracle):
     st = bzx.stats()
     assert out == bz2.compress(dup, 9)
     assert st.n_open_buckets > 0 and st.n_open_left == 0 and st.n_resume_left == 0 and st.n_from_scratch == 0
+    assert st.n_unsorted == 0       # the optimistic initial sort's check held for every bucket (wg_radix_sort_opt)
     runs = big[:120_000] + (b"ab" * 700 + b"c") * 200 + big[120_000:200_000] + b"?"
     out = bzx.compress_buffer(runs, 9)
     st = bzx.stats()
