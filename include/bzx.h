@@ -104,8 +104,11 @@ int bzx_split_rle1(bzx_ctx *ctx, const uint8_t *raw, size_t len, int level, uint
  * crosses PCIe.  cap >= len + len/50 + 4096.  Alignment: d_raw 16 bytes, d_out 4 bytes (BZX_E_PARAM otherwise,
  * with the reason in bzx_last_error): a view into a larger device tensor must start on such a boundary.
  * Cost: blocks that are an exact power u^k (inputs made of one repeated byte and the like) need
- * libbz2's tie order among identical rotations: ~0.1 s for an all-zero block (many copies of a long unit: seconds)
- * instead of milliseconds; such blocks of one call are handled side by side.
+ * libbz2's tie order among identical rotations: ~0.1 s for an all-zero block instead of milliseconds, and up to
+ * seconds for many copies of a long unit (measured worst case over the committed sweep of units of 1..30,011 bytes:
+ * 29 copies of a 30,011-byte unit, 4.1 s for that one block).  Such blocks of one call are handled side by side; the
+ * context serialises its entry points, so other callers of the SAME context wait that long (use one context per
+ * caller where that matters).
  */
 int bzx_compress_device(bzx_ctx *ctx, const void *d_raw, size_t len, int level, void *d_out, size_t cap,
                         size_t *out_len);
