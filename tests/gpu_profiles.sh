@@ -15,7 +15,7 @@ stats() {      # name, bench args...
     rm -rf $out/tmp_$name
     rocprofv3 --kernel-trace --stats --output-format csv -d $out/tmp_$name -o k -- python3 $BENCH "$@" > $out/${name}_bench.log 2>&1
     cp $(find $out/tmp_$name -name '*kernel_stats.csv' | head -1) $out/${tag}_${name}kernel_stats.csv
-    tail -1 $out/${name}_bench.log > $out/${tag}_${name}bench_line.json
+    grep "^{\"metric\"" $out/${name}_bench.log | tail -1 > $out/${tag}_${name}bench_line.json
     rm -rf $out/tmp_$name
 }
 pmc() {        # name, counters...
