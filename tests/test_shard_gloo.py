@@ -22,8 +22,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,kind,nbytes,mode", [(2, "text", 230000, "whole"), (4, "runs", 600000, "whole"),
-                                                    (4, "runs", 700000, "scan"), (2, "dups", 420000, "whole"),
+@pytest.mark.parametrize("world,kind,nbytes,mode", [(2, "text", 230000, "whole"), (4, "runs", 900000, "whole"),
+                                                    (4, "runs", 900000, "scan"), (2, "dups", 420000, "whole"),
                                                     (2, "border", 450000, "scan"), (4, "border", 600000, "scan")])
 def test_round_robin_sharding(oracle, world, kind, nbytes, mode):
     # mode "scan": the sharded split analysis (bzx_shard_scan_* + all-gathers of 24 B per tile), with runs of more than
