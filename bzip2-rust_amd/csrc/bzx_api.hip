@@ -19,7 +19,7 @@
 #include "bzx_device.h"
 
 void bzx_launch_bwt(const BzxBatch &B, uint32_t grid, hipStream_t stream);
-void bzx_launch_bsplit(const BzxBatch &B, uint32_t grid, hipStream_t stream);
+void bzx_launch_bsplit(const BzxBatch &B, uint32_t grid, uint32_t grid_deep, hipStream_t stream);
 void bzx_launch_bsort(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_pack_max(const BzxBatch &B, uint32_t world, uint64_t *d_out, hipStream_t stream);
@@ -217,6 +217,7 @@ static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk, uint32_t nslab = 0)
         if ((rc = dev_alloc(ctx, ctx->slabs, &B.bk_list, (size_t)cap * BZX_BK_PER_BLOCK))) return rc;
         B.bk_cap = cap * BZX_BK_PER_BLOCK;
         if ((rc = dev_alloc(ctx, ctx->slabs, &B.rk_list, (size_t)B.bk_cap * 2))) return rc;
+        if ((rc = dev_alloc(ctx, ctx->slabs, &B.deep_list, (size_t)cap * BZX_DEEP_PER_BLOCK * 4 * 2))) return rc;
         if ((rc = dev_alloc(ctx, ctx->slabs, &B.isa2, (size_t)cap * 2 * BZX_MAX_N))) return rc;
         B.rk_blocks = cap;
     }
@@ -436,7 +437,11 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         // holds whole blocks (one L2 per block)
         B.bk_affine = nblk >= 64 ? 1u : 0u;
         HIP_TRY(ctx, hipMemsetAsync(B.bk_list, 0, items * sizeof(BzxBucket), ctx->stream));
-        bzx_launch_bsplit(B, nblk < ncu ? nblk : ncu, ctx->stream);
+        // the two lists of oversized bins (deeper split levels): zeroed, an item reserved but not written is an empty one
+        const size_t deep_all = (size_t)ctx->cap_slabs * BZX_DEEP_PER_BLOCK;
+        B.deep_cap = (uint32_t)((size_t)nblk * BZX_DEEP_PER_BLOCK < deep_all ? (size_t)nblk * BZX_DEEP_PER_BLOCK : deep_all);
+        HIP_TRY(ctx, hipMemsetAsync(B.deep_list, 0, (size_t)B.deep_cap * 2 * 16, ctx->stream));
+        bzx_launch_bsplit(B, nblk < ncu ? nblk : ncu, ncu, ctx->stream);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_b1, ctx->stream));
         // Blocks the split kernel refused (oversized bins beyond its depth / split limits: a handful in real data)
         // are sorted from scratch by the general sorter, one workgroup each, 10-60 ms: started right away on the

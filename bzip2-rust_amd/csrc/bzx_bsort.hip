@@ -260,6 +260,99 @@ __device__ __forceinline__ void block_redo(const BzxBatch &B, uint32_t b)
         B.redo_list[atomicAdd(&B.counters[BZX_CTR_REDO], 1u)] = b;
 }
 
+// ---- deeper levels.  An oversized bin (more than BS_C rotations share its prefix) is split again by its next BS_BIN2
+// bits into the other record buffer (its key field holds exactly those bits first); the records are re-keyed from P at
+// the new depth.  The bins wait in a ring in LDS: b_bcast[3] counts the entries pushed (bucket_emit), `done` the entries
+// taken.  Round 2 let the workgroup of a block work its ring off alone, and on real files a few blocks with hundreds of
+// such bins set the time of the whole split kernel (python sources: 13 ms for 3.4 ms of average work per block).  Now
+// the entries from `flush_from` on are handed to the list of level `push_lvl` (>= 0) as far as it has room, and a
+// launch of bzx_bsplit_deep_kernel per level deals them to all compute units; past the last level (or a full list)
+// a workgroup finishes its subtree itself.  Returns false when the block has to be sorted from scratch.
+struct BzxDeepItem {
+    uint32_t blk, st, cnt, dbits;           // st: first rank | buffer << 31; dbits: depth in key bits | bits per symbol << 16
+};
+
+__device__ bool deep_process(const BzxBatch &B, uint32_t b, uint32_t j_, uint32_t n, uint32_t bits, const uint8_t *__restrict__ P,
+                             uint64_t *__restrict__ rec_a, uint64_t *__restrict__ rec_b, uint32_t done, uint32_t flush_from,
+                             int push_lvl)
+{
+    const uint32_t tid = threadIdx.x;
+    bool ok = true;
+    while (ok) {
+        const uint32_t nbig = b_bcast[3];
+        __syncthreads();
+        if (done >= nbig) break;
+        if (push_lvl >= 0 && done >= flush_from) {
+            const uint32_t np = nbig - done;
+            if (tid == 0) b_bcast[5] = atomicAdd(&B.counters[BZX_CTR_DEEP_CNT + push_lvl], np);
+            __syncthreads();
+            const uint32_t at = b_bcast[5];
+            __syncthreads();
+            if (at + np <= B.deep_cap) {
+                BzxDeepItem *dl = reinterpret_cast<BzxDeepItem *>(B.deep_list) + (size_t)(push_lvl & 1) * B.deep_cap + at;
+                for (uint32_t q = tid; q < np; q += BS_NT) {
+                    const uint32_t r = (done + q) % BS_MAX_BIG;
+                    BzxDeepItem it;
+                    it.blk = b;
+                    it.st = b_big[r][0];
+                    it.cnt = b_big[r][1];
+                    it.dbits = b_big[r][2] | (bits << 16);
+                    dl[q] = it;
+                }
+                __syncthreads();
+                break;
+            }
+            push_lvl = -1;                        // (no room: the reserved entries stay empty, this workgroup goes on)
+        }
+        const uint32_t st = b_big[done % BS_MAX_BIG][0], cnt = b_big[done % BS_MAX_BIG][1], depth = b_big[done % BS_MAX_BIG][2];
+        done++;
+        if (tid == 0) b_bcast[6] = atomicAdd(reinterpret_cast<uint32_t *>(&B.blk[b].pack_word), 1u);      // splits spent on the block
+        __syncthreads();                                      // (the slot may be reused by this split's pushes)
+        const uint32_t spent = b_bcast[6];
+        const uint32_t base = st & 0x7fffffffu, buf = st >> 31;
+        const uint64_t *__restrict__ src = (buf ? rec_b : rec_a) + base;
+        uint64_t *__restrict__ dst = (buf ? rec_a : rec_b) + base;
+        // a whole turn of the block is shared (periodic blocks): general sorter, from scratch
+        if (depth + BS_BIN2 + 32 >= n * bits) {
+            ok = false;
+            break;
+        }
+        // still oversized after BS_MAX_DEPTH key bits, or BS_MAX_SPLITS splits spent on this block (near-identical
+        // copies of content): the bin stays one group
+        if (depth + BS_BIN2 > BS_MAX_DEPTH || spent >= BS_MAX_SPLITS) {
+            emit_giant(B, b, rec_a, rec_b, st, cnt, depth, bits);
+            continue;
+        }
+        constexpr uint32_t NB2 = 1u << BS_BIN2;
+        for (uint32_t i = tid; i < NB2 + (NB2 >> 5); i += BS_NT) b_tab[i] = 0;
+        if (tid == 0) b_bcast[1] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += BS_NT) atomicAdd(&TAB((uint32_t)(src[i] >> (64 - BS_BIN2))), 1u);
+        __syncthreads();
+        const uint32_t nbk = form_buckets<(int)NB2>(cnt);
+        if (nbk == 0) {
+            ok = false;
+            break;
+        }
+        bucket_setup<BS_BIN2>(nbk);
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += BS_NT) {
+            const uint64_t r = src[i];
+            const uint32_t k = TAB((uint32_t)(r >> (64 - BS_BIN2)));
+            uint32_t x = REC_IDX(r) * bits + depth + b_b0[k];           // bit offsets wrap at the block end
+            if (x >= n * bits) x -= n * bits;
+            const uint32_t key = (uint32_t)(pk_window_bit(P, x) >> 32);
+            const uint32_t slot = atomicAdd(&b_cur[k], 1u);
+            dst[b_start[k] + slot] = ((uint64_t)key << 32) | (r & 0xFFFFFFFFull);
+        }
+        __syncthreads();
+        ok = bucket_emit<BS_BIN2>(B, b, j_, nbk, base, buf ^ 1u, depth, bits, done);
+        DIAG_COUNT(104, 1);
+        DIAG_COUNT(105, cnt);
+    }
+    return ok;
+}
+
 __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
 {
     const uint32_t tid = threadIdx.x;
@@ -285,6 +378,7 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
             b_bcast[1] = 0;
             b_bcast[3] = 0;
             b_bcast[4] = 0;
+            B.blk[b].pack_word = 0;              // (until the stream is laid out: deeper splits spent on the block)
             B.blk[b].n_mtf = 0xFFFFFFFFu;        // (until the MTF stage: smallest depth, in symbols, at which a bucket gave up)
             B.blk[b].n_groups = 0;               // (until the Huffman stage: buckets that gave up and are still open)
         }
@@ -469,59 +563,53 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
         bool ok = bucket_emit<BS_BIN1>(B, b, j_, nbk, 0, 0, 0, bits, 0);
         DIAG_STAMP(102);
 
-        // ---- deeper levels: every oversized bin is split by its next BS_BIN2 bits into the other record buffer
-        // (its key field holds exactly those bits first); the records are re-keyed from P at the new depth
-        uint32_t done = 0;
-        while (ok) {
-            const uint32_t nbig = b_bcast[3];
-            __syncthreads();
-            if (done >= nbig) break;
-            const uint32_t st = b_big[done % BS_MAX_BIG][0], cnt = b_big[done % BS_MAX_BIG][1], depth = b_big[done % BS_MAX_BIG][2];
-            done++;
-            __syncthreads();                                      // (the slot may be reused by this split's pushes)
-            const uint32_t base = st & 0x7fffffffu, buf = st >> 31;
-            const uint64_t *__restrict__ src = (buf ? rec_b : rec_a) + base;
-            uint64_t *__restrict__ dst = (buf ? rec_a : rec_b) + base;
-            // a whole turn of the block is shared (periodic blocks): general sorter, from scratch
-            if (depth + BS_BIN2 + 32 >= n * bits) {
-                ok = false;
-                break;
-            }
-            // still oversized after BS_MAX_DEPTH key bits, or BS_MAX_SPLITS splits spent on this block (near-identical
-            // copies of content; every split costs tens of microseconds on this one workgroup): the bin stays one group
-            if (depth + BS_BIN2 > BS_MAX_DEPTH || done > BS_MAX_SPLITS) {
-                emit_giant(B, b, rec_a, rec_b, st, cnt, depth, bits);
-                continue;
-            }
-            constexpr uint32_t NB2 = 1u << BS_BIN2;
-            for (uint32_t i = tid; i < NB2 + (NB2 >> 5); i += BS_NT) b_tab[i] = 0;
-            if (tid == 0) b_bcast[1] = 0;
-            __syncthreads();
-            for (uint32_t i = tid; i < cnt; i += BS_NT) atomicAdd(&TAB((uint32_t)(src[i] >> (64 - BS_BIN2))), 1u);
-            __syncthreads();
-            nbk = form_buckets<(int)NB2>(cnt);
-            if (nbk == 0) {
-                ok = false;
-                break;
-            }
-            bucket_setup<BS_BIN2>(nbk);
-            __syncthreads();
-            for (uint32_t i = tid; i < cnt; i += BS_NT) {
-                const uint64_t r = src[i];
-                const uint32_t k = TAB((uint32_t)(r >> (64 - BS_BIN2)));
-                uint32_t x = REC_IDX(r) * bits + depth + b_b0[k];           // bit offsets wrap at the block end
-                if (x >= n * bits) x -= n * bits;
-                const uint32_t key = (uint32_t)(pk_window_bit(P, x) >> 32);
-                const uint32_t slot = atomicAdd(&b_cur[k], 1u);
-                dst[b_start[k] + slot] = ((uint64_t)key << 32) | (r & 0xFFFFFFFFull);
-            }
-            __syncthreads();
-            ok = bucket_emit<BS_BIN2>(B, b, j_, nbk, base, buf ^ 1u, depth, bits, done);
-            DIAG_COUNT(104, 1);
-            DIAG_COUNT(105, cnt);
-        }
+        // ---- deeper levels: every oversized bin is split again by its next BS_BIN2 bits (deep_process): by the launches
+        // of the deep-split kernel that follow, any workgroup on any bin of any block, as far as the levels' lists reach
+        if (ok) ok = deep_process(B, b, j_, n, bits, P, rec_a, rec_b, 0, 0, BZX_DEEP_LEVELS > 0 ? 0 : -1);
         DIAG_STAMP(103);
         if (!ok) DIAG_COUNT(107, 1);
+        if (!ok && tid == 0) block_redo(B, b);
+        __syncthreads();
+    }
+    DIAG_FLUSH();
+}
+
+// One level of the deeper splits: the oversized bins the level before (or the split kernel) listed, any workgroup
+// on any bin.  Children that are still oversized go to the next level's list; after the last level a workgroup
+// works its bin's subtree off itself.  An empty list: every workgroup leaves at once.
+__global__ __launch_bounds__(BS_NT) void bzx_bsplit_deep_kernel(BzxBatch B)
+{
+    const uint32_t tid = threadIdx.x, lvl = B.deep_lvl;
+    const uint32_t listed = B.counters[BZX_CTR_DEEP_CNT + lvl];
+    const uint32_t n_items = listed < B.deep_cap ? listed : B.deep_cap;
+    if (n_items == 0) return;
+    DIAG_T0();
+    const BzxDeepItem *list = reinterpret_cast<const BzxDeepItem *>(B.deep_list) + (size_t)(lvl & 1u) * B.deep_cap;
+    for (;;) {
+        if (tid == 0) b_bcast[0] = atomicAdd(&B.counters[BZX_CTR_DEEP_FETCH + lvl], 1u);
+        __syncthreads();
+        const uint32_t i = b_bcast[0];
+        __syncthreads();
+        if (i >= n_items) break;
+        const BzxDeepItem d = list[i];
+        if (d.cnt == 0) continue;                                              // reserved, never written
+        const uint32_t b = d.blk;
+        if (__atomic_load_n(&B.blk[b].status, __ATOMIC_RELAXED) & BZX_ST_REDO) continue;   // sorted from scratch anyway
+        const uint32_t n = B.blk[b].n, bits = d.dbits >> 16;
+        const size_t sb = BZX_SLAB(B, b);
+        const uint8_t *__restrict__ P = B.pk + sb * BZX_PK_STRIDE;
+        uint64_t *__restrict__ rec_a = B.rec_a + sb * BZX_MAX_N;
+        uint64_t *__restrict__ rec_b = B.rec_b + sb * BZX_MAX_N;
+        if (tid == 0) {
+            b_bcast[3] = 1;                                                    // the ring holds this bin
+            b_bcast[4] = 0;
+            b_big[0][0] = d.st;
+            b_big[0][1] = d.cnt;
+            b_big[0][2] = d.dbits & 0xFFFFu;
+        }
+        __syncthreads();
+        const bool ok = deep_process(B, b, (b - B.blk_first) / B.blk_step, n, bits, P, rec_a, rec_b, 0, 1,
+                                     lvl + 1 < BZX_DEEP_LEVELS ? (int)lvl + 1 : -1);
         if (!ok && tid == 0) block_redo(B, b);
         __syncthreads();
     }
@@ -1817,9 +1905,14 @@ void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream)
     static_assert(1 + RK_ROUNDS <= BZX_N_COUNTERS - BZX_CTR_RK_FETCH, "one fetch counter per launch");
 }
 
-void bzx_launch_bsplit(const BzxBatch &B, uint32_t grid, hipStream_t stream)
+void bzx_launch_bsplit(const BzxBatch &B, uint32_t grid, uint32_t grid_deep, hipStream_t stream)
 {
     hipLaunchKernelGGL(bzx_bsplit_kernel, dim3(grid), dim3(BS_NT), 0, stream, B);
+    BzxBatch D = B;
+    for (uint32_t lvl = 0; lvl < BZX_DEEP_LEVELS; lvl++) {          // (a launch with an empty list is a no-op of a few microseconds)
+        D.deep_lvl = lvl;
+        hipLaunchKernelGGL(bzx_bsplit_deep_kernel, dim3(grid_deep), dim3(BS_NT), 0, stream, D);
+    }
 }
 
 void bzx_launch_bsort(const BzxBatch &B, uint32_t grid, hipStream_t stream)

@@ -30,6 +30,13 @@
 #define BZX_CTR_PERIODIC 5         // blocks flagged periodic
 #define BZX_CTR_BK_ITEMS 8         // (unused since the work list became eight lists)
 #define BZX_CTR_BK_LIST0 40        // [40..47] bucket work items in each of the eight lists (BzxBatch.bk_list)
+#ifndef BZX_DEEP_LEVELS
+#define BZX_DEEP_LEVELS 2          // launches of the deep-split kernel (levels of oversized bins dealt over the whole chip), <= 8:
+                                   // two levels take the tail off real files (6 were no better), an empty launch costs ~30 us
+#endif
+#define BZX_DEEP_PER_BLOCK 128u    // items of a level's list per block of the batch (a full list: the workgroup splits on by itself)
+#define BZX_CTR_DEEP_CNT 48        // [48..55] oversized bins listed for each level
+#define BZX_CTR_DEEP_FETCH 56      // [56..63] ... fetched
 #define BZX_CTR_BK_FETCH 9         // ... fetched by the bucket sort kernel
 #define BZX_CTR_REDO 10            // blocks handed to the general sorter
 #define BZX_CTR_SPLIT_FETCH 11     // blocks fetched by the split kernel
@@ -124,6 +131,9 @@ struct BzxBatch {
     uint32_t *resume_list;  // [nblk] blocks the general sorter finishes (BZX_ST_RESUME)
     uint32_t *rk_list;      // [2 * allocated items] indices into bk_list of the buckets that gave up; [bk_cap + i]: tied ranks of
                             // bucket rk_list[i] (entries of its compact list, see the rank rounds)
+    uint32_t *deep_list;    // [2][deep_cap] items of 16 B: oversized bins of the level being split / of the next one (zeroed per batch)
+    uint32_t deep_cap;
+    uint32_t deep_lvl;      // level of this launch of the deep-split kernel
     uint32_t *isa2;         // [blocks][2][BZX_MAX_N] two rank arrays per block in resume state (index: its place in resume_list)
     uint32_t rk_blocks;     // blocks that get rank arrays (all; stress builds: a few)
     uint32_t rk_fetch;      // rank rounds: this launch's work-fetch counter (index into counters)
