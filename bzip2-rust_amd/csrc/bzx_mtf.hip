@@ -28,7 +28,7 @@ __shared__ __attribute__((aligned(16))) uint8_t m_pool[2 * MTF_LIST_BYTES + 32];
 #define m_list (m_pool + MTF_LIST_BYTES)
 __shared__ uint16_t m_reccnt[MTF_NT];
 #define MTF_GROUP 32                                   // chunks per group of the two-level start-list walk
-__shared__ uint8_t m_super[(MTF_NT / MTF_GROUP) * 264];   // recency list of every group of 32 chunks
+__shared__ __attribute__((aligned(8))) uint8_t m_super[(MTF_NT / MTF_GROUP) * 264 + 8];   // recency list of every group of 32 chunks
 __shared__ uint16_t m_supercnt[MTF_NT / MTF_GROUP];
 __shared__ uint32_t m_inuse[256];
 __shared__ uint8_t m_seq[256];
@@ -162,11 +162,27 @@ __device__ __forceinline__ void mtf_recency(const uint8_t *__restrict__ L, uint3
     *cnt_out = (uint16_t)cnt;
 }
 
+// Distinct symbols of rec[0 .. rc) that `seen` does not hold yet, appended to dst (8 entries per load: the recency lists
+// of large alphabets live in global memory, see the kernel).
+template <int NW>
+__device__ __forceinline__ void mtf_take_new(const uint8_t *rec, uint32_t rc, SeenSet<NW> &seen, uint8_t *dst, uint32_t &cnt)
+{
+    for (uint32_t k0 = 0; k0 < rc; k0 += 8) {
+        const uint64_t w = *reinterpret_cast<const uint64_t *>(rec + k0);       // (lists are 8-byte aligned and padded)
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t s = (uint32_t)(w >> (8 * k)) & 255u;
+            if (k0 + k < rc && !seen.test_set(s)) dst[cnt++] = (uint8_t)s;
+        }
+    }
+}
+
 // (a) recency list of every group of MTF_GROUP chunks (one lane per group); (b) the MTF list at my chunk start:
 // earlier chunks of my group, then earlier groups, most recent first, then the never-seen symbols in id order.
-template <int NW>
+// recs: the chunks' recency lists (LDS, or global memory for large alphabets), lists: the working lists (LDS).
+template <int NW, typename RecPtr>
 __device__ __forceinline__ void mtf_start_lists(uint32_t tid, uint32_t nch_used, uint32_t n_in_use, uint32_t stride,
-                                                bool have_chunk)
+                                                bool have_chunk, RecPtr recs, uint8_t *lists)
 {
     if (tid * MTF_GROUP < nch_used) {
         SeenSet<NW> seen;
@@ -177,12 +193,7 @@ __device__ __forceinline__ void mtf_start_lists(uint32_t tid, uint32_t nch_used,
         const uint32_t g_hi = g_lo + MTF_GROUP < nch_used ? g_lo + MTF_GROUP : nch_used;
         for (uint32_t c = g_hi; c > g_lo && cnt < n_in_use;) {
             c--;
-            const uint8_t *rec = m_rec + c * stride;
-            const uint32_t rc = m_reccnt[c];
-            for (uint32_t k = 0; k < rc; k++) {
-                const uint32_t s = rec[k];
-                if (!seen.test_set(s)) sup[cnt++] = (uint8_t)s;
-            }
+            mtf_take_new<NW>(recs + c * stride, m_reccnt[c], seen, sup, cnt);
         }
         m_supercnt[tid] = (uint16_t)cnt;
     }
@@ -191,25 +202,15 @@ __device__ __forceinline__ void mtf_start_lists(uint32_t tid, uint32_t nch_used,
         SeenSet<NW> seen;
         seen.clear();
         uint32_t cnt = 0;
-        uint8_t *lst = m_list + tid * stride;
+        uint8_t *lst = lists + tid * stride;
         const uint32_t g = tid / MTF_GROUP;
         for (uint32_t c = tid; c > g * MTF_GROUP && cnt < n_in_use;) {
             c--;
-            const uint8_t *rec = m_rec + c * stride;
-            const uint32_t rc = m_reccnt[c];
-            for (uint32_t k = 0; k < rc; k++) {
-                const uint32_t s = rec[k];
-                if (!seen.test_set(s)) lst[cnt++] = (uint8_t)s;
-            }
+            mtf_take_new<NW>(recs + c * stride, m_reccnt[c], seen, lst, cnt);
         }
         for (uint32_t gg = g; gg > 0 && cnt < n_in_use;) {
             gg--;
-            const uint8_t *sup = m_super + gg * 264;
-            const uint32_t rc = m_supercnt[gg];
-            for (uint32_t k = 0; k < rc; k++) {
-                const uint32_t s = sup[k];
-                if (!seen.test_set(s)) lst[cnt++] = (uint8_t)s;
-            }
+            mtf_take_new<NW>(m_super + gg * 264, m_supercnt[gg], seen, lst, cnt);
         }
         // symbols never seen so far keep the initial (ascending) order
         for (uint32_t s = 0; s < n_in_use && cnt < n_in_use; s++)
@@ -318,7 +319,14 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         // ---- 2. chunking of the heads: a list is stride64 (odd) 8-byte words per chunk, lists fit 72 KiB
         const uint32_t stride64 = ((n_in_use + 7) / 8) | 1u;      // odd word stride: conflict-free 64-bit LDS access
         const uint32_t stride = stride64 * 8;
-        uint32_t nch = MTF_LIST_BYTES / stride;
+        // Large alphabets: 72 KB of working lists are 279 lanes' worth at 256 symbols -- one wave per SIMD, and the walk
+        // through a list is a chain of dependent LDS round trips that nothing hides.  So the recency lists (written
+        // once, read once, in between) move out to global memory -- the symbol slab of the block, idle until the
+        // zero-run pass -- and the working lists get the whole pool: twice the lanes.
+        const bool big = n_in_use > 64;
+        uint8_t *grec = reinterpret_cast<uint8_t *>(V);            // [nch][stride] (<= 1,024 x 264 B of the 1.8 MB slab)
+        uint8_t *lists = big ? m_pool : m_list;
+        uint32_t nch = (big ? 2 * MTF_LIST_BYTES : MTF_LIST_BYTES) / stride;
         if (nch > MTF_NT) nch = MTF_NT;
         uint32_t csz = (nh + nch - 1) / nch;
         csz = (csz + 15u) & ~15u;
@@ -330,16 +338,16 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         // ---- 3. recency list of my chunk: distinct symbols by last occurrence, most recent first
         if (have_chunk) {
             if (n_in_use <= 64) mtf_recency<1>(H, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid]);
-            else if (n_in_use <= 128) mtf_recency<2>(H, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid]);
-            else mtf_recency<4>(H, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid]);
+            else if (n_in_use <= 128) mtf_recency<2>(H, c_lo, c_hi, n_in_use, grec + tid * stride, &m_reccnt[tid]);
+            else mtf_recency<4>(H, c_lo, c_hi, n_in_use, grec + tid * stride, &m_reccnt[tid]);
         }
-        __syncthreads();
+        __syncthreads();                 // (also orders the global recency lists: all waves of a workgroup share the unit's L1)
         MTF_STAMP(33);
 
         // ---- 4. MTF list at every chunk start (two-level walk over the recency lists)
-        if (n_in_use <= 64) mtf_start_lists<1>(tid, nch_used, n_in_use, stride, have_chunk);
-        else if (n_in_use <= 128) mtf_start_lists<2>(tid, nch_used, n_in_use, stride, have_chunk);
-        else mtf_start_lists<4>(tid, nch_used, n_in_use, stride, have_chunk);
+        if (n_in_use <= 64) mtf_start_lists<1>(tid, nch_used, n_in_use, stride, have_chunk, (const uint8_t *)m_rec, lists);
+        else if (n_in_use <= 128) mtf_start_lists<2>(tid, nch_used, n_in_use, stride, have_chunk, (const uint8_t *)grec, lists);
+        else mtf_start_lists<4>(tid, nch_used, n_in_use, stride, have_chunk, (const uint8_t *)grec, lists);
         __syncthreads();
         MTF_STAMP(34);
 
@@ -347,13 +355,13 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         // The first 8 list entries live in a register (byte 0 = front); deeper entries in LDS as 8-byte words,
         // searched and shifted one word at a time.
         if (have_chunk && n_in_use <= 32) {
-            const uint64_t *lst64 = reinterpret_cast<const uint64_t *>(m_list + tid * stride);
+            const uint64_t *lst64 = reinterpret_cast<const uint64_t *>(lists + tid * stride);
             if (n_in_use <= 8) mtf_ranks_regs<1>(H, H, c_lo, c_hi, lst64, m_seq);
             else if (n_in_use <= 16) mtf_ranks_regs<2>(H, H, c_lo, c_hi, lst64, m_seq);
             else if (n_in_use <= 24) mtf_ranks_regs<3>(H, H, c_lo, c_hi, lst64, m_seq);
             else mtf_ranks_regs<4>(H, H, c_lo, c_hi, lst64, m_seq);
         } else if (have_chunk) {
-            uint64_t *lst64 = reinterpret_cast<uint64_t *>(m_list + tid * stride);
+            uint64_t *lst64 = reinterpret_cast<uint64_t *>(lists + tid * stride);
             uint64_t w = lst64[0];
             const uint64_t ones = 0x0101010101010101ull, highs = 0x8080808080808080ull;
             uint4 nxt = *reinterpret_cast<const uint4 *>(H + c_lo);
