@@ -34,15 +34,21 @@ __shared__ uint32_t h_scratch[2 * HUF_NW];
 __shared__ uint32_t h_bcast[4];
 __shared__ uint32_t h_acc[4];       // [0] selector bits, [1] table bits, [2] payload bits
 
-// libbz2 hbMakeCodeLengths for table t (one lane).
+// libbz2 hbMakeCodeLengths for table t, by ONE WAVE: the heap (whose order decides ties) is built and
+// emptied by lane 0 exactly as libbz2 does it; what has no order -- the initial weights, the depth of every leaf
+// (a walk up the parent links: a quarter of the time at 258 symbols), the halving of the weights -- is spread over
+// the 64 lanes.
 __device__ void make_code_lengths(int t, int32_t alpha, int32_t max_len)
 {
     int32_t *heap = h_heap[t], *weight = h_weight[t], *parent = h_parent[t];
-    for (int32_t i = 0; i < alpha; i++) {
+    const int32_t lane = (int32_t)bzx_lane();
+    for (int32_t i = lane; i < alpha; i += 64) {
         const uint32_t f = h_rfreq[t][i];
         weight[i + 1] = (int32_t)((f == 0 ? 1u : f) << 8);
     }
     for (;;) {
+        bzx_wave_sync();
+        if (lane == 0) {
         int32_t n_nodes = alpha, n_heap = 0;
         heap[0] = 0;
         weight[0] = 0;
@@ -93,8 +99,10 @@ __device__ void make_code_lengths(int t, int32_t alpha, int32_t max_len)
             }
             heap[zz] = tmp;
         }
+        }
+        bzx_wave_sync();
         bool too_long = false;
-        for (int32_t i = 1; i <= alpha; i++) {
+        for (int32_t i = 1 + lane; i <= alpha; i += 64) {
             int32_t j = 0, k = i;
             while (parent[k] >= 0) {
                 k = parent[k];
@@ -103,8 +111,8 @@ __device__ void make_code_lengths(int t, int32_t alpha, int32_t max_len)
             h_len[t][i - 1] = (uint8_t)j;
             if (j > max_len) too_long = true;
         }
-        if (!too_long) break;
-        for (int32_t i = 1; i <= alpha; i++) {
+        if (!__ballot(too_long)) break;
+        for (int32_t i = 1 + lane; i <= alpha; i += 64) {
             int32_t j = weight[i] >> 8;
             j = 1 + (j / 2);
             weight[i] = j << 8;
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(HUF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             }
             __syncthreads();
             HUF_STAMP(41);
-            if (lane == 0 && wave < n_groups) make_code_lengths((int)wave, (int32_t)alpha, 17);
+            if (wave < n_groups) make_code_lengths((int)wave, (int32_t)alpha, 17);      // (a wave per table)
             __syncthreads();
             HUF_STAMP(42);
         }
