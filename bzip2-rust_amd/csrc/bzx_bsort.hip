@@ -861,6 +861,8 @@ __device__ __attribute__((noinline)) void wg_radix_sort_opt(uint32_t cnt, int lo
 }
 
 // The same for s_w[base .. base+s), s <= BS_MED, by ONE wave (all 64 lanes call it together; no workgroup barriers).
+// TICKETS: ranks from returning LDS atomics (see wg_radix_sort_opt; the caller checks the order) instead of ballots.
+template <bool TICKETS>
 __device__ __attribute__((noinline)) void wave_radix_sort(uint32_t base, uint32_t s, int lo, int hi)
 {
     constexpr uint32_t ROWS = BS_MED / 64;
@@ -890,7 +892,10 @@ __device__ __attribute__((noinline)) void wave_radix_sort(uint32_t base, uint32_
 #pragma unroll
         for (uint32_t j = 0; j < ROWS; j++) {
             old[j] = rk[j] = 0;
-            if (j < rows) wave_rank(wc, (uint32_t)(v[j] >> shift) & (SK_ND - 1), j * 64 + lane < s, lane, old[j], rk[j]);
+            if (j < rows) {
+                if (TICKETS) old[j] = bzx_lds_ticket(&wc[(uint32_t)(v[j] >> shift) & (SK_ND - 1)], j * 64 + lane < s);
+                else wave_rank(wc, (uint32_t)(v[j] >> shift) & (SK_ND - 1), j * 64 + lane < s, lane, old[j], rk[j]);
+            }
         }
         {
             // exclusive scan of the SK_ND counts: SK_ND/64 digits per lane
@@ -965,6 +970,28 @@ __device__ __forceinline__ bool any_big(uint32_t base, uint32_t s, uint32_t t, u
         big |= !tiny_bounds(base + e, gs, ge);
     }
     return big;
+}
+
+// One wave orders s_w[base .. base+s) by bits [lo, 64) and flags the new group starts.  Ticket-ranked passes first;
+// their result is used only if the keys come out non-decreasing (else: never seen; the ballot-ranked passes redo it).
+__device__ __forceinline__ void wave_sort_mark(uint32_t base, uint32_t s, int lo, uint32_t lane)
+{
+    wave_radix_sort<true>(base, s, lo, 64);
+    lds_order();
+    uint32_t diff = 0;
+    bool bad = false;
+    for (uint32_t e = 1 + lane, k = 0; e < s; e += 64, k++) {
+        const uint64_t a = s_w[base + e] >> lo, b = s_w[base + e - 1] >> lo;
+        bad |= a < b;
+        diff |= (uint32_t)(a != b) << k;
+    }
+    if (__ballot(bad)) {
+        wave_radix_sort<false>(base, s, lo, 64);
+        mark_changes(base, s, lo, lane, 64);
+        return;
+    }
+    for (uint32_t e = 1 + lane, k = 0; e < s; e += 64, k++)
+        if ((diff >> k) & 1u) fset(base + e);
 }
 
 // The list of tied ranks lives in the key halves of s_x, which are dead once the initial sort has set the group-start
@@ -1248,13 +1275,9 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
                     k = __shfl(k, 0);
                     if (k >= nmed) break;
                     const uint32_t e = s_med[k], gs = e & 0xFFFFu, sz = e >> 16;
-                    wave_radix_sort(gs, sz, 48, 64);
-                    mark_changes(gs, sz, 48, lane, 64);
+                    wave_sort_mark(gs, sz, 48, lane);
                     lds_order();
-                    if (__ballot(any_big(gs, sz, lane, 64))) {
-                        wave_radix_sort(gs, sz, 14, 64);
-                        mark_changes(gs, sz, 14, lane, 64);
-                    }
+                    if (__ballot(any_big(gs, sz, lane, 64))) wave_sort_mark(gs, sz, 14, lane);
                 }
                 for (uint32_t k = 0; k < nlarge; k++) {
                     const uint32_t e = s_large[k], gs = e & 0xFFFFu, sz = e >> 16;
@@ -1764,13 +1787,9 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
                 k = __shfl(k, 0);
                 if (k >= nmed) break;
                 const uint32_t e = s_med[k], gs = e & 0xFFFFu, sz = e >> 16;
-                wave_radix_sort(gs, sz, 48, 64);
-                mark_changes(gs, sz, 48, lane, 64);
+                wave_sort_mark(gs, sz, 48, lane);
                 lds_order();
-                if (__ballot(any_big(gs, sz, lane, 64))) {
-                    wave_radix_sort(gs, sz, 14, 64);
-                    mark_changes(gs, sz, 14, lane, 64);
-                }
+                if (__ballot(any_big(gs, sz, lane, 64))) wave_sort_mark(gs, sz, 14, lane);
             }
             for (uint32_t k = 0; k < nlarge; k++) {
                 const uint32_t e = s_large[k], gs = e & 0xFFFFu, sz = e >> 16;
