@@ -1483,6 +1483,13 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bfill_kernel(Bzx
 //                 settled) -- singletons of the list are exactly those.
 // Any workgroup takes any open bucket (16 per fetch; finished ones are skipped by their flags).
 #define RK_CHUNK 16
+// The 16 lanes that test the items also fetch what a round needs to know about each -- bucket, block, list length:
+// five dependent global loads, once for the chunk instead of one chain per bucket.
+struct RkMeta {
+    uint32_t bi, T, blk, start, cnt, n, rk, h0;     // item, tied ranks, block, first rank, bucket size, block size, rank arrays, give-up depth
+};
+__shared__ RkMeta s_meta[RK_CHUNK];
+
 __device__ __forceinline__ uint32_t rk_fetch_chunk(const BzxBatch &B, uint32_t n_items, uint32_t &open)
 {
     __shared__ uint32_t s_fetch[2];
@@ -1492,7 +1499,21 @@ __device__ __forceinline__ uint32_t rk_fetch_chunk(const BzxBatch &B, uint32_t n
         if (threadIdx.x == 0) base = atomicAdd(&B.counters[B.rk_fetch], (uint32_t)RK_CHUNK);
         base = __shfl(base, 0);
         const uint32_t i = base + threadIdx.x;
-        const bool op = threadIdx.x < RK_CHUNK && i < n_items && !(B.bk_list[B.rk_list[i]].dbits >> 31);
+        bool op = false;
+        if (threadIdx.x < RK_CHUNK && i < n_items) {
+            RkMeta m;
+            m.bi = B.rk_list[i];
+            m.T = B.rk_list[B.bk_cap + i];
+            const BzxBucket it = B.bk_list[m.bi];
+            op = !(it.dbits >> 31);
+            m.blk = it.blk;
+            m.start = it.start & 0x7fffffffu;
+            m.cnt = it.cnt & 0x7fffffffu;
+            m.n = B.blk[it.blk].n;
+            m.rk = B.blk[it.blk].n_selectors;
+            m.h0 = B.blk[it.blk].n_mtf;
+            s_meta[threadIdx.x] = m;
+        }
         const uint64_t m = __ballot(op);
         if (threadIdx.x == 0) {
             s_fetch[0] = base;
@@ -1544,9 +1565,9 @@ __global__ __launch_bounds__(SK_NT) void bzx_brank_init_kernel(BzxBatch B)
         }
         const uint32_t i = chunk0 + (uint32_t)__builtin_ctz(open_items);
         open_items &= open_items - 1u;
-        const uint32_t bi = B.rk_list[i];
-        const uint32_t b = B.bk_list[bi].blk, cnt = B.bk_list[bi].cnt & 0x7fffffffu, start = B.bk_list[bi].start & 0x7fffffffu;
-        const uint32_t rk = B.blk[b].n_selectors;
+        const RkMeta &mt = s_meta[i - chunk0];
+        const uint32_t b = mt.blk, cnt = mt.cnt, start = mt.start;
+        const uint32_t rk = mt.rk;
         uint32_t *__restrict__ isa0 = rank_array(B, rk, 0), *__restrict__ isa1 = rank_array(B, rk, 1);
         if (!isa0) continue;
         const uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
@@ -1583,14 +1604,15 @@ __global__ __launch_bounds__(SK_NT) void bzx_brank_init_kernel(BzxBatch B)
 __device__ __forceinline__ void rank_round_wave(const BzxBatch &B, uint32_t i)
 {
     const uint32_t lane = bzx_lane(), wave = bzx_wave();
-    const uint32_t bi = bzx_bcast0(B.rk_list[i]);
-    const uint32_t T = bzx_bcast0(B.rk_list[B.bk_cap + i]);
-    const uint32_t b = bzx_bcast0(B.bk_list[bi].blk), start = bzx_bcast0(B.bk_list[bi].start) & 0x7fffffffu;
-    const uint32_t rk = bzx_bcast0(B.blk[b].n_selectors);
+    const RkMeta &mt = s_meta[i & (RK_CHUNK - 1)];          // (chunks start at multiples of RK_CHUNK)
+    const uint32_t bi = bzx_bcast0(mt.bi);
+    const uint32_t T = bzx_bcast0(mt.T);
+    const uint32_t b = bzx_bcast0(mt.blk), start = bzx_bcast0(mt.start);
+    const uint32_t rk = bzx_bcast0(mt.rk);
     const uint32_t *__restrict__ isa_r = rank_array(B, rk, B.rk_h_shift & 1u);
     uint32_t *__restrict__ isa_w = rank_array(B, rk, (B.rk_h_shift & 1u) ^ 1u);
-    const uint32_t n = bzx_bcast0(B.blk[b].n);
-    const uint64_t h64 = (uint64_t)bzx_bcast0(B.blk[b].n_mtf) << B.rk_h_shift;
+    const uint32_t n = bzx_bcast0(mt.n);
+    const uint64_t h64 = (uint64_t)bzx_bcast0(mt.h0) << B.rk_h_shift;
     if (!isa_r || h64 >= n) return;
     const uint32_t h = (uint32_t)h64;
     uint32_t *__restrict__ cl = reinterpret_cast<uint32_t *>(B.rec_b + BZX_SLAB(B, b) * BZX_MAX_N + start);
@@ -1682,7 +1704,7 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
             uint32_t small = 0, seen = 0;
             for (uint32_t m = open_items; m; m &= m - 1u) {
                 const uint32_t k = (uint32_t)__builtin_ctz(m);
-                if (uni(B.rk_list[B.bk_cap + chunk0 + k]) <= 64u) {
+                if (uni(s_meta[k].T) <= 64u) {
                     small |= 1u << k;
                     if ((seen++ & (SK_NW - 1)) == (threadIdx.x >> 6)) rank_round_wave(B, chunk0 + k);
                 }
@@ -1695,14 +1717,15 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
         }
         const uint32_t i = chunk0 + (uint32_t)__builtin_ctz(open_items);
         open_items &= open_items - 1u;
-        const uint32_t bi = uni(B.rk_list[i]);
-        const uint32_t T = uni(B.rk_list[B.bk_cap + i]);
-        const uint32_t b = uni(B.bk_list[bi].blk), start = uni(B.bk_list[bi].start) & 0x7fffffffu;
-        const uint32_t rk = uni(B.blk[b].n_selectors);
+        const RkMeta &mt = s_meta[i - chunk0];
+        const uint32_t bi = uni(mt.bi);
+        const uint32_t T = uni(mt.T);
+        const uint32_t b = uni(mt.blk), start = uni(mt.start);
+        const uint32_t rk = uni(mt.rk);
         const uint32_t *__restrict__ isa_r = rank_array(B, rk, B.rk_h_shift & 1u);
         uint32_t *__restrict__ isa_w = rank_array(B, rk, (B.rk_h_shift & 1u) ^ 1u);
-        const uint32_t n = uni(B.blk[b].n);
-        const uint64_t h64 = (uint64_t)uni(B.blk[b].n_mtf) << B.rk_h_shift;
+        const uint32_t n = uni(mt.n);
+        const uint64_t h64 = (uint64_t)uni(mt.h0) << B.rk_h_shift;
         if (!isa_r || h64 >= n) continue;                           // (left to the general sorter: see bzx_launch_brank)
         const uint32_t h = (uint32_t)h64;
         uint32_t *__restrict__ cl = reinterpret_cast<uint32_t *>(B.rec_b + BZX_SLAB(B, b) * BZX_MAX_N + start);
