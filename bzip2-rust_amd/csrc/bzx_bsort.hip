@@ -1317,19 +1317,23 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
                     }
                 }
                 if (j < nrow) {
-                    uint32_t r = 0, eq = 0;
+                    // r: members below my word (key, then position: a total order); rk: members below my KEY alone -- any word
+                    // with a smaller key is below my word with its position bits cleared.  r == rk: nobody with my key
+                    // precedes me, I start a (sub)group.
+                    uint32_t r = 0, rk = 0;
+                    const uint64_t myc = my[j] & ~W_POS_MASK;
                     for (uint32_t i = 0; i < sz; i += 4) {
                         uint64_t wq[4];
 #pragma unroll
                         for (uint32_t k = 0; k < 4; k++) wq[k] = s_w[a_ + (i + k < sz ? i + k : sz - 1)];
 #pragma unroll
                         for (uint32_t k = 0; k < 4; k++) {
-                            const bool lt = i + k < sz && wq[k] < my[j];
-                            r += lt;
-                            eq += lt && ((wq[k] ^ my[j]) >> 14) == 0;
+                            const bool in = i + k < sz;
+                            r += in && wq[k] < my[j];
+                            rk += in && wq[k] < myc;
                         }
                     }
-                    if (sz) dst_[j] = (a_ + r) | (eq ? 0u : 0x80000000u);
+                    if (sz) dst_[j] = (a_ + r) | (r != rk ? 0u : 0x80000000u);
                 }
             }
             __syncthreads();
@@ -1849,19 +1853,20 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
                 }
             }
             if (j < nrow) {
-                uint32_t r = 0, eq = 0;
+                uint32_t r = 0, rk = 0;                   // (see the sort kernel's counting tier)
+                const uint64_t myc = my[j] & ~W_POS_MASK;
                 for (uint32_t i2 = 0; i2 < sz; i2 += 4) {
                     uint64_t wq[4];
 #pragma unroll
                     for (uint32_t k = 0; k < 4; k++) wq[k] = s_w[a_ + (i2 + k < sz ? i2 + k : sz - 1)];
 #pragma unroll
                     for (uint32_t k = 0; k < 4; k++) {
-                        const bool lt = i2 + k < sz && wq[k] < my[j];
-                        r += lt;
-                        eq += lt && ((wq[k] ^ my[j]) >> 14) == 0;
+                        const bool in = i2 + k < sz;
+                        r += in && wq[k] < my[j];
+                        rk += in && wq[k] < myc;
                     }
                 }
-                if (sz) dst_[j] = (a_ + r) | (eq ? 0u : 0x80000000u);
+                if (sz) dst_[j] = (a_ + r) | (r != rk ? 0u : 0x80000000u);
             }
         }
         __syncthreads();
