@@ -630,7 +630,7 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_deep_kernel(BzxBatch B)
 static_assert(BS_C % SK_NT == 0 && BS_E >= 1 && BS_E <= 8, "bucket capacity");
 
 __shared__ uint64_t s_x[BS_C];               // records, in rank order after the initial sort (never moved again)
-__shared__ uint64_t s_w[BS_C];               // rank p: [current 50 key bits | index into s_x of the record ranked p:14]
+__shared__ uint64_t s_w[BS_C + 4];           // rank p: [current 50 key bits | index into s_x of the record ranked p:14] (+ read slack)
 __shared__ uint32_t s_cnt[SK_NW][SK_ND];     // per-wave digit counters
 __shared__ uint32_t s_dbase[SK_ND];
 __shared__ uint32_t s_part[4];
@@ -1325,7 +1325,7 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
                     for (uint32_t i = 0; i < sz; i += 4) {
                         uint64_t wq[4];
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; k++) wq[k] = s_w[a_ + (i + k < sz ? i + k : sz - 1)];
+                        for (uint32_t k = 0; k < 4; k++) wq[k] = s_w[a_ + i + k];       // (past the group: read, not counted)
 #pragma unroll
                         for (uint32_t k = 0; k < 4; k++) {
                             const bool in = i + k < sz;
@@ -1858,7 +1858,7 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
                 for (uint32_t i2 = 0; i2 < sz; i2 += 4) {
                     uint64_t wq[4];
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; k++) wq[k] = s_w[a_ + (i2 + k < sz ? i2 + k : sz - 1)];
+                    for (uint32_t k = 0; k < 4; k++) wq[k] = s_w[a_ + i2 + k];          // (past the group: read, not counted)
 #pragma unroll
                     for (uint32_t k = 0; k < 4; k++) {
                         const bool in = i2 + k < sz;
