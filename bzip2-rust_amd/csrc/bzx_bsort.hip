@@ -34,8 +34,10 @@
 #define BS_C 2048                       // rotations per bucket (records in LDS)
 #endif
 #define BS_FW (BS_C / 64)               // 64-bit words of group-start flags
-#define BS_ISO (BS_C / 3)               // bins above this stay alone
-#define BS_CP (BS_C - BS_ISO)           // merged bins must start inside one window of this many ranks
+#define BS_ISO (BS_C / 3)               // bins above this always stay alone
+#ifndef BS_ISO_SHIFT
+#define BS_ISO_SHIFT 5                  // a smaller limit is taken while it isolates less than n >> this many rotations
+#endif
 #ifndef BS_BIN1
 #define BS_BIN1 15                      // bits of the level-1 bins
 #endif
@@ -113,41 +115,68 @@ __shared__ uint32_t b_inuse[256];
 __shared__ uint8_t b_seq[256];
 __shared__ uint32_t b_scratch[2 * BS_NW];
 __shared__ uint32_t b_lbase[8];              // first item of this block's buckets in each of the eight work lists
-__shared__ uint32_t b_bcast[8];              // [0] block, [2] item base, [3] oversized bins pushed so far, [4] ring overflow
+__shared__ uint32_t b_bcast[12];             // [0] block, [2] item base, [3] oversized bins pushed so far, [4] ring overflow,
+                                             // [8..10] rotations in bins a smaller isolation limit would leave alone
 __shared__ uint32_t b_big[BS_MAX_BIG][3];    // oversized bins: {start | buffer << 31, cnt, depth bits}
 
 #define TAB(b) b_tab[(b) + ((b) >> 5)]
 
-// Bins [0, BINS) counted in TAB -> buckets.  A new bucket starts at bin b when b or b-1 is above BS_ISO, or when
-// the bin's first rank lies in another BS_CP-window than its predecessor's: merged buckets stay below BS_C.
+// Bins [0, BINS) counted in TAB -> buckets.  With an isolation limit ISO, a new bucket starts at bin b when b or b-1 is
+// above ISO, or when the bin's first rank lies in another (BS_C - ISO)-window than its predecessor's: a merged bucket is
+// at most one window plus one bin <= BS_C.  The smaller ISO, the wider the window and the fuller the buckets, but bins
+// between ISO and BS_ISO then make small buckets of their own: the smallest of BS_C/8, /6, /4 that leaves fewer than
+// total >> BS_ISO_SHIFT rotations in such bins is taken, else BS_ISO.  (b_bcast[8..10] are zero on entry.)
 // Returns the number of buckets (0: more than BS_MAX_BK); TAB(b) = bucket of bin b afterwards.
+template <int ISO, int PER>
+__device__ __forceinline__ void bucket_flags(const uint32_t (&c)[PER], uint32_t bin0, uint32_t excl, uint32_t prevc, uint32_t &fl, uint32_t &nf)
+{
+    constexpr uint32_t CP = BS_C - ISO;
+    uint32_t s = excl, ps = excl - prevc, pc = prevc;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const bool f = (bin0 + k == 0) || c[k] > (uint32_t)ISO || pc > (uint32_t)ISO || (s / CP != ps / CP);
+        fl |= (uint32_t)f << k;
+        nf += f;
+        ps = s;
+        s += c[k];
+        pc = c[k];
+    }
+}
+
 template <int BINS, bool TAB16 = false>
 __device__ __forceinline__ uint32_t form_buckets(uint32_t total)
 {
     constexpr int PER = BINS / BS_NT;
     const uint32_t tid = threadIdx.x, bin0 = tid * PER;
-    uint32_t c[PER], sum = 0;
+    uint32_t c[PER], sum = 0, e8 = 0, e6 = 0, e4 = 0;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         c[k] = TAB(bin0 + k);
         sum += c[k];
+        const uint32_t m = c[k] <= BS_ISO ? c[k] : 0u;
+        e8 += m > BS_C / 8 ? m : 0u;
+        e6 += m > BS_C / 6 ? m : 0u;
+        e4 += m > BS_C / 4 ? m : 0u;
     }
     const uint32_t prevc = tid ? TAB(bin0 - 1) : 0u;
-    uint32_t tot;
-    const uint32_t excl = bzx_block_excl_sum<BS_NT>(sum, b_scratch, tot);
-    uint32_t fl = 0, nf = 0;
-    {
-        uint32_t s = excl, ps = excl - prevc, pc = prevc;
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const bool f = (bin0 + k == 0) || c[k] > BS_ISO || pc > BS_ISO || (s / BS_CP != ps / BS_CP);
-            fl |= (uint32_t)f << k;
-            nf += f;
-            ps = s;
-            s += c[k];
-            pc = c[k];
+    if (__any(e8 != 0)) {
+        e8 = bzx_wave_incl_sum(e8);
+        e6 = bzx_wave_incl_sum(e6);
+        e4 = bzx_wave_incl_sum(e4);
+        if (bzx_lane() == 63) {
+            atomicAdd(&b_bcast[8], e8);
+            if (e6) atomicAdd(&b_bcast[9], e6);
+            if (e4) atomicAdd(&b_bcast[10], e4);
         }
     }
+    uint32_t tot;
+    const uint32_t excl = bzx_block_excl_sum<BS_NT>(sum, b_scratch, tot);      // (its first barrier publishes b_bcast[8..10])
+    const uint32_t allow = total >> BS_ISO_SHIFT;
+    uint32_t fl = 0, nf = 0;
+    if (b_bcast[8] <= allow) bucket_flags<BS_C / 8>(c, bin0, excl, prevc, fl, nf);
+    else if (b_bcast[9] <= allow) bucket_flags<BS_C / 6>(c, bin0, excl, prevc, fl, nf);
+    else if (b_bcast[10] <= allow) bucket_flags<BS_C / 4>(c, bin0, excl, prevc, fl, nf);
+    else bucket_flags<BS_ISO>(c, bin0, excl, prevc, fl, nf);
     uint32_t nbk;
     const uint32_t fexcl = bzx_block_excl_sum<BS_NT>(nf, b_scratch, nbk);
     if (nbk > BS_MAX_BK) return 0;
@@ -326,6 +355,7 @@ __device__ bool deep_process(const BzxBatch &B, uint32_t b, uint32_t j_, uint32_
         constexpr uint32_t NB2 = 1u << BS_BIN2;
         for (uint32_t i = tid; i < NB2 + (NB2 >> 5); i += BS_NT) b_tab[i] = 0;
         if (tid == 0) b_bcast[1] = 0;
+        if (tid < 3) b_bcast[8 + tid] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < cnt; i += BS_NT) atomicAdd(&TAB((uint32_t)(src[i] >> (64 - BS_BIN2))), 1u);
         __syncthreads();
@@ -378,6 +408,7 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
             b_bcast[1] = 0;
             b_bcast[3] = 0;
             b_bcast[4] = 0;
+            b_bcast[8] = b_bcast[9] = b_bcast[10] = 0;
             B.blk[b].pack_word = 0;              // (until the stream is laid out: deeper splits spent on the block)
             B.blk[b].n_mtf = 0xFFFFFFFFu;        // (until the MTF stage: smallest depth, in symbols, at which a bucket gave up)
             B.blk[b].n_groups = 0;               // (until the Huffman stage: buckets that gave up and are still open)
