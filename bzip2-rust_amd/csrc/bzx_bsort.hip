@@ -275,10 +275,9 @@ __device__ __forceinline__ void emit_giant(const BzxBatch &B, uint32_t blk, uint
     }
     if (tid == 0) {
         atomicMin(&B.blk[blk].n_mtf, depth / bits);
-        if ((atomicOr(&B.blk[blk].status, BZX_ST_RESUME) & BZX_ST_RESUME) == 0) {
+        B.blk[blk].n_selectors = 0xFFFFFFFFu;                      // no rank array
+        if ((atomicOr(&B.blk[blk].status, BZX_ST_RESUME) & BZX_ST_RESUME) == 0)
             B.resume_list[atomicAdd(&B.counters[BZX_CTR_RESUME], 1u)] = blk;
-            B.blk[blk].n_selectors = 0xFFFFFFFFu;                  // no rank array
-        }
     }
     __syncthreads();
 }
@@ -412,6 +411,7 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
             B.blk[b].pack_word = 0;              // (until the stream is laid out: deeper splits spent on the block)
             B.blk[b].n_mtf = 0xFFFFFFFFu;        // (until the MTF stage: smallest depth, in symbols, at which a bucket gave up)
             B.blk[b].n_groups = 0;               // (until the Huffman stage: buckets that gave up and are still open)
+            B.blk[b].n_selectors = (uint32_t)BZX_SLAB(B, b);      // (until then: the block's pair of rank arrays)
         }
         __syncthreads();
         {
@@ -1393,18 +1393,29 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
             // rank rounds do not finish the block -- and the block is queued for the rank rounds.  The fill pass
             // writes the same for the buckets of such a block that did finish (every rank its own group) and enters
             // their -- final -- ranks into both rank arrays of the block.
+            // A bucket that gives up enters the rank of its group's first member for every rank into the first rank
+            // array -- the one round 0 reads -- and for the ranks that are alone in their group (final) into the second
+            // as well: the tied ones are written there by round 0.
             uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
-            const uint32_t rk = fail ? 0xFFFFFFFFu : uni(B.blk[b].n_selectors);
+            const uint32_t rk = uni(B.blk[b].n_selectors);
             uint32_t *__restrict__ isa0 = rank_array(B, rk, 0), *__restrict__ isa1 = rank_array(B, rk, 1);
 #pragma unroll
             for (uint32_t j = 0; j < BS_E; j++) {
                 const uint32_t p = j * SK_NT + tid;
                 if (p < cnt) {
                     const uint32_t rot = REC_IDX(s_x[(uint32_t)(s_w[p] & W_POS_MASK)]);
-                    sax[p] = (uint64_t)rot | ((uint64_t)fbit(p) << 32);
+                    const uint32_t f0 = fbit(p);
+                    sax[p] = (uint64_t)rot | ((uint64_t)f0 << 32);
                     if (isa0) {
-                        isa0[rot] = start + p;
-                        isa1[rot] = start + p;
+                        uint32_t head = p;
+                        if (!f0) {
+                            uint32_t wi = p >> 6;
+                            uint64_t w = s_f[wi] & (~0ull >> (63u - (p & 63u)));
+                            while (!w) w = s_f[--wi];              // (rank 0 of the bucket starts a group)
+                            head = wi * 64 + 63u - (uint32_t)__builtin_clzll(w);
+                        }
+                        isa0[rot] = start + head;
+                        if (f0 && fbit(p + 1)) isa1[rot] = start + head;
                     }
                 }
             }
@@ -1451,11 +1462,8 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
                     B.rk_list[B.bk_cap + ri] = total;                // tied ranks of the bucket
                     atomicAdd(&B.counters[BZX_CTR_RK_OPEN], 1u);
                     atomicAdd(&B.blk[b].n_groups, 1u);
-                    if ((atomicOr(&B.blk[b].status, BZX_ST_RESUME) & BZX_ST_RESUME) == 0) {
-                        const uint32_t k = atomicAdd(&B.counters[BZX_CTR_RESUME], 1u);
-                        B.resume_list[k] = b;
-                        B.blk[b].n_selectors = k;
-                    }
+                    if ((atomicOr(&B.blk[b].status, BZX_ST_RESUME) & BZX_ST_RESUME) == 0)
+                        B.resume_list[atomicAdd(&B.counters[BZX_CTR_RESUME], 1u)] = b;
                 }
             }
         }
@@ -1508,7 +1516,8 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bfill_kernel(Bzx
 // leftover groups -- all inside one bucket -- are refined by the ranks of the rotations h symbols ahead (h = the
 // block's smallest give-up depth, doubling every round): the refinement round of the sort kernel with
 // ISA[(rotation + h) mod n] in place of the next 50 key bits, on the compact list.
-//   init launch : every bucket that gave up enters the group-head rank of each of its ranks into BOTH rank arrays.
+//   before      : a bucket that gives up (sort kernel) enters the group-head rank of each of its ranks into rank array
+//                 0, and the ranks that are alone in their group into array 1 too.
 //   round r     : ONE launch.  A bucket loads its list, gathers from rank array r & 1, orders its groups, enters the
 //                 new group-head ranks into rank array (r + 1) & 1 and stores the list back without the entries that
 //                 left.  Nobody reads the array that is being written, so a reader never mixes ranks of two depths
@@ -1584,52 +1593,6 @@ __device__ __forceinline__ uint32_t slot_prefix(const uint64_t *keep, uint32_t n
         }
     }
     return total;
-}
-
-__global__ __launch_bounds__(SK_NT) void bzx_brank_init_kernel(BzxBatch B)
-{
-    if (B.counters[BZX_CTR_RK_OPEN] == 0) return;
-    const uint32_t n_items = B.counters[BZX_CTR_RK_ITEMS];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t chunk0 = 0, open_items = 0;
-    for (;;) {
-        if (open_items == 0) {
-            chunk0 = rk_fetch_chunk(B, n_items, open_items);
-            if (chunk0 >= n_items) break;
-            continue;
-        }
-        const uint32_t i = chunk0 + (uint32_t)__builtin_ctz(open_items);
-        open_items &= open_items - 1u;
-        const RkMeta &mt = s_meta[i - chunk0];
-        const uint32_t b = mt.blk, cnt = mt.cnt, start = mt.start;
-        const uint32_t rk = mt.rk;
-        uint32_t *__restrict__ isa0 = rank_array(B, rk, 0), *__restrict__ isa1 = rank_array(B, rk, 1);
-        if (!isa0) continue;
-        const uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
-        uint32_t rot[BS_E];
-        __syncthreads();
-#pragma unroll
-        for (uint32_t j = 0; j < BS_E; j++) {
-            const uint32_t p = j * SK_NT + tid;
-            const uint64_t v = p < cnt ? sax[p] : (1ull << 32);
-            rot[j] = (uint32_t)v & 0xFFFFFu;
-            const uint64_t m = __ballot(p >= cnt || ((v >> 32) & 1ull));
-            if (lane == 0) s_f[j * SK_NW + wave] = m;
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t j = 0; j < BS_E; j++) {
-            const uint32_t p = j * SK_NT + tid;
-            if (p < cnt) {
-                uint32_t wi = p >> 6;
-                uint64_t w = s_f[wi] & (~0ull >> (63u - (p & 63u)));
-                while (!w) w = s_f[--wi];                          // (rank 0 of the bucket starts a group)
-                const uint32_t head = start + wi * 64 + 63u - (uint32_t)__builtin_clzll(w);
-                isa0[rot[j]] = head;
-                isa1[rot[j]] = head;
-            }
-        }
-    }
 }
 
 // One rank round of a bucket whose list has at most 64 entries, by ONE wave (slot = lane; no workgroup barrier, no
@@ -1974,7 +1937,6 @@ void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream)
     };
     R.rk_h_shift = 0;
     R.rk_last = 0;
-    go(bzx_brank_init_kernel);
     for (uint32_t r = 0; r < RK_ROUNDS; r++) {
         R.rk_h_shift = r;
         R.rk_last = r + 1 == RK_ROUNDS;

@@ -25,8 +25,8 @@ __shared__ uint8_t h_len[6][BZX_MAX_ALPHA + 2];
 // per symbol, ONE 8-byte word: low half len0 | len1<<10 | len2<<20, high half len3 | len4<<10 | len5<<20
 __shared__ uint2 h_lenAB[BZX_MAX_ALPHA + 2];
 __shared__ uint32_t h_rfreq[6][BZX_MAX_ALPHA + 2];
-__shared__ int32_t h_heap[6][BZX_MAX_ALPHA + 2];
-__shared__ int32_t h_weight[6][BZX_MAX_ALPHA * 2];
+__shared__ __attribute__((aligned(16))) uint64_t h_heap[6][BZX_MAX_ALPHA + 2];     // [weight:32 | node:32]
+__shared__ int32_t h_weight[6][BZX_MAX_ALPHA + 2];                                  // leaves
 __shared__ int32_t h_parent[6][BZX_MAX_ALPHA * 2];
 __shared__ uint32_t h_code[6][BZX_MAX_ALPHA + 2];
 __shared__ uint32_t h_part[6][2];   // initial partition [gs, ge] per table
@@ -36,11 +36,15 @@ __shared__ uint32_t h_acc[4];       // [0] selector bits, [1] table bits, [2] pa
 
 // libbz2 hbMakeCodeLengths for table t, by ONE WAVE: the heap (whose order decides ties) is built and
 // emptied by lane 0 exactly as libbz2 does it; what has no order -- the initial weights, the depth of every leaf
-// (a walk up the parent links: a quarter of the time at 258 symbols), the halving of the weights -- is spread over
-// the 64 lanes.
+// (a walk up the parent links), the halving of the weights -- is spread over the 64 lanes.
+// The heap walk is one chain of dependent LDS round trips, so it is laid out to need as few as possible: a heap entry
+// carries its node's weight ([weight:32 | node:32]; libbz2 looks the weight up through the node), and the two children
+// of a node are one aligned 16-byte read.  Weights of inner nodes exist only inside their heap entries.  (At 258
+// symbols the walk took 0.8 ms per table and pass with separate heap and weight arrays: three quarters of the stage.)
 __device__ void make_code_lengths(int t, int32_t alpha, int32_t max_len)
 {
-    int32_t *heap = h_heap[t], *weight = h_weight[t], *parent = h_parent[t];
+    uint64_t *heap = h_heap[t];
+    int32_t *weight = h_weight[t], *parent = h_parent[t];
     const int32_t lane = (int32_t)bzx_lane();
     for (int32_t i = lane; i < alpha; i += 64) {
         const uint32_t f = h_rfreq[t][i];
@@ -49,56 +53,58 @@ __device__ void make_code_lengths(int t, int32_t alpha, int32_t max_len)
     for (;;) {
         bzx_wave_sync();
         if (lane == 0) {
-        int32_t n_nodes = alpha, n_heap = 0;
-        heap[0] = 0;
-        weight[0] = 0;
-        parent[0] = -2;
-        for (int32_t i = 1; i <= alpha; i++) {
-            parent[i] = -1;
-            n_heap++;
-            heap[n_heap] = i;
-            int32_t zz = n_heap;
-            const int32_t tmp = heap[zz], wt = weight[tmp];
-            while (wt < weight[heap[zz >> 1]]) {
-                heap[zz] = heap[zz >> 1];
-                zz >>= 1;
-            }
-            heap[zz] = tmp;
-        }
-        while (n_heap > 1) {
-            int32_t n12[2];
-            for (int rep = 0; rep < 2; rep++) {
-                n12[rep] = heap[1];
-                heap[1] = heap[n_heap];
-                n_heap--;
-                int32_t zz = 1;
-                const int32_t tmp = heap[zz], wt = weight[tmp];
+            int32_t n_nodes = alpha, n_heap = 0;
+            heap[0] = 0;                                   // (node 0, weight 0: the sentinel above the root)
+            parent[0] = -2;
+            auto up = [&](uint64_t e) {                    // libbz2 UPHEAP of the entry placed at n_heap
+                int32_t zz = n_heap;
+                const uint32_t wt = (uint32_t)(e >> 32);
                 for (;;) {
-                    int32_t yy = zz << 1;
-                    if (yy > n_heap) break;
-                    if (yy < n_heap && weight[heap[yy + 1]] < weight[heap[yy]]) yy++;
-                    if (wt < weight[heap[yy]]) break;
-                    heap[zz] = heap[yy];
-                    zz = yy;
+                    const uint64_t pe = heap[zz >> 1];
+                    if (!(wt < (uint32_t)(pe >> 32))) break;
+                    heap[zz] = pe;
+                    zz >>= 1;
                 }
-                heap[zz] = tmp;
+                heap[zz] = e;
+            };
+            for (int32_t i = 1; i <= alpha; i++) {
+                parent[i] = -1;
+                n_heap++;
+                up(((uint64_t)(uint32_t)weight[i] << 32) | (uint32_t)i);
             }
-            n_nodes++;
-            parent[n12[0]] = parent[n12[1]] = n_nodes;
-            const uint32_t w1 = (uint32_t)weight[n12[0]], w2 = (uint32_t)weight[n12[1]];
-            const uint32_t d1 = w1 & 0xffu, d2 = w2 & 0xffu;
-            weight[n_nodes] = (int32_t)(((w1 & 0xffffff00u) + (w2 & 0xffffff00u)) | (1u + (d1 > d2 ? d1 : d2)));
-            parent[n_nodes] = -1;
-            n_heap++;
-            heap[n_heap] = n_nodes;
-            int32_t zz = n_heap;
-            const int32_t tmp = heap[zz], wt = weight[tmp];
-            while (wt < weight[heap[zz >> 1]]) {
-                heap[zz] = heap[zz >> 1];
-                zz >>= 1;
+            while (n_heap > 1) {
+                uint64_t e12[2];
+                for (int rep = 0; rep < 2; rep++) {        // twice: take the root, DOWNHEAP the last entry from there
+                    e12[rep] = heap[1];
+                    const uint64_t e = heap[n_heap];
+                    n_heap--;
+                    int32_t zz = 1;
+                    const uint32_t wt = (uint32_t)(e >> 32);
+                    for (;;) {
+                        int32_t yy = zz << 1;
+                        if (yy > n_heap) break;
+                        const uint4 two = *reinterpret_cast<const uint4 *>(heap + yy);     // children yy, yy + 1 (yy is even)
+                        uint32_t cw = two.y, cn = two.x;
+                        if (yy < n_heap && two.w < two.y) {
+                            yy++;
+                            cw = two.w;
+                            cn = two.z;
+                        }
+                        if (wt < cw) break;
+                        heap[zz] = ((uint64_t)cw << 32) | cn;
+                        zz = yy;
+                    }
+                    heap[zz] = e;
+                }
+                n_nodes++;
+                parent[(uint32_t)e12[0]] = parent[(uint32_t)e12[1]] = n_nodes;
+                const uint32_t w1 = (uint32_t)(e12[0] >> 32), w2 = (uint32_t)(e12[1] >> 32);
+                const uint32_t d1 = w1 & 0xffu, d2 = w2 & 0xffu;
+                const uint32_t wn = ((w1 & 0xffffff00u) + (w2 & 0xffffff00u)) | (1u + (d1 > d2 ? d1 : d2));
+                parent[n_nodes] = -1;
+                n_heap++;
+                up(((uint64_t)wn << 32) | (uint32_t)n_nodes);
             }
-            heap[zz] = tmp;
-        }
         }
         bzx_wave_sync();
         bool too_long = false;
@@ -237,30 +243,32 @@ __global__ __launch_bounds__(HUF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             HUF_STAMP(42);
         }
 
-        // ---- canonical codes (huffman.rs:361-374), one lane per table
-        if (lane == 0 && wave < n_groups) {
+        // ---- canonical codes (huffman.rs:361-374), one wave per table: for every length in turn, the symbols of that
+        // length take consecutive codes in symbol order (ballot + count of the lanes below)
+        if (wave < n_groups) {
             const int t = (int)wave;
-            int32_t min_len = 32, max_len = 0;
-            for (uint32_t i = 0; i < alpha; i++) {
-                const int32_t l = h_len[t][i];
-                if (l > max_len) max_len = l;
-                if (l < min_len) min_len = l;
+            uint32_t mx = 0, mn_inv = 0, tb = 0;
+            for (uint32_t i = lane; i < alpha; i += 64) {
+                const uint32_t l = h_len[t][i], prev = h_len[t][i ? i - 1 : 0];
+                mx = l > mx ? l : mx;
+                mn_inv = 32u - l > mn_inv ? 32u - l : mn_inv;
+                tb += 2u * (l > prev ? l - prev : prev - l) + 1u;      // coding-table section: 5 + sum(2|delta| + 1)
             }
+            const uint32_t max_len = (uint32_t)__shfl((int)bzx_wave_incl_max(mx), 63);
+            const uint32_t min_len = 32u - (uint32_t)__shfl((int)bzx_wave_incl_max(mn_inv), 63);
+            tb = bzx_wave_incl_sum(tb);
+            if (lane == 63) atomicAdd(&h_acc[1], 5u + tb);
             uint32_t vec = 0;
-            for (int32_t nn = min_len; nn <= max_len; nn++) {
-                for (uint32_t i = 0; i < alpha; i++)
-                    if (h_len[t][i] == nn) h_code[t][i] = vec++;
+            for (uint32_t nn = min_len; nn <= max_len; nn++) {
+                for (uint32_t i0 = 0; i0 < alpha; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const bool hit = i < alpha && h_len[t][i] == nn;
+                    const uint64_t m = __ballot(hit);
+                    if (hit) h_code[t][i] = vec + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    vec += (uint32_t)__popcll(m);
+                }
                 vec <<= 1;
             }
-            // coding-table section size: 5 + sum(2|delta| + 1)
-            uint32_t bits = 5;
-            int32_t curr = h_len[t][0];
-            for (uint32_t i = 0; i < alpha; i++) {
-                const int32_t l = h_len[t][i];
-                bits += 2u * (uint32_t)(l > curr ? l - curr : curr - l) + 1u;
-                curr = l;
-            }
-            atomicAdd(&h_acc[1], bits);
         }
         __syncthreads();
         for (uint32_t i = tid; i < 6 * 260; i += HUF_NT) {

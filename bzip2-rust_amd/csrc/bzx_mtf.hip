@@ -27,9 +27,10 @@ __shared__ __attribute__((aligned(16))) uint8_t m_pool[2 * MTF_LIST_BYTES + 32];
 #define m_rec m_pool
 #define m_list (m_pool + MTF_LIST_BYTES)
 __shared__ uint16_t m_reccnt[MTF_NT];
-#define MTF_GROUP 32                                   // chunks per group of the two-level start-list walk
-__shared__ __attribute__((aligned(8))) uint8_t m_super[(MTF_NT / MTF_GROUP) * 264 + 8];   // recency list of every group of 32 chunks
+#define MTF_GROUP 64                                   // chunks per group of the start lists: the chunks of one wave
+__shared__ __attribute__((aligned(8))) uint8_t m_super[(MTF_NT / MTF_GROUP) * 264 + 8];   // recency list of every group of chunks
 __shared__ uint16_t m_supercnt[MTF_NT / MTF_GROUP];
+__shared__ uint64_t m_supermask[(MTF_NT / MTF_GROUP) * 4];        // the symbols of every group's list
 __shared__ uint32_t m_inuse[256];
 __shared__ uint8_t m_seq[256];
 __shared__ uint32_t m_freq[BZX_MAX_ALPHA + 2];
@@ -134,7 +135,7 @@ __device__ __forceinline__ void mtf_ranks_regs(const uint8_t *L, uint8_t *R, uin
 // Recency list of chunk [c_lo, c_hi): distinct symbols by last occurrence, most recent first.
 template <int NW>
 __device__ __forceinline__ void mtf_recency(const uint8_t *__restrict__ L, uint32_t c_lo, uint32_t c_hi, uint32_t n_in_use,
-                                            uint8_t *rec, uint16_t *cnt_out)
+                                            uint8_t *rec, uint16_t *cnt_out, uint64_t *mask_out)
 {
     SeenSet<NW> seen;
     seen.clear();
@@ -160,62 +161,164 @@ __device__ __forceinline__ void mtf_recency(const uint8_t *__restrict__ L, uint3
         i0 -= 16;
     }
     *cnt_out = (uint16_t)cnt;
+#pragma unroll
+    for (int i = 0; i < NW; i++) mask_out[i] = seen.w[i];              // the symbols the chunk holds
 }
 
-// Distinct symbols of rec[0 .. rc) that `seen` does not hold yet, appended to dst (8 entries per load: the recency lists
-// of large alphabets live in global memory, see the kernel).
+// Is symbol `sym` in the set m (NW words)?
 template <int NW>
-__device__ __forceinline__ void mtf_take_new(const uint8_t *rec, uint32_t rc, SeenSet<NW> &seen, uint8_t *dst, uint32_t &cnt)
+__device__ __forceinline__ bool mtf_in_set(const uint64_t *m, uint32_t sym)
 {
-    for (uint32_t k0 = 0; k0 < rc; k0 += 8) {
-        const uint64_t w = *reinterpret_cast<const uint64_t *>(rec + k0);       // (lists are 8-byte aligned and padded)
+    uint64_t x = m[0];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t s = (uint32_t)(w >> (8 * k)) & 255u;
-            if (k0 + k < rc && !seen.test_set(s)) dst[cnt++] = (uint8_t)s;
+    for (int i = 1; i < NW; i++) x = (sym >> 6) == (uint32_t)i ? m[i] : x;
+    return (x >> (sym & 63u)) & 1ull;
+}
+
+// One merge step by a whole wave: the entries src[0 .. n) that are not in the set `skip` are appended to dst at `at`, in
+// order (entry k belongs to lane k & 63: a ballot and a count of the lanes below place it).
+template <int NW, typename SrcPtr>
+__device__ __forceinline__ void mtf_append_new(SrcPtr src, uint32_t n, const uint64_t *skip, uint8_t *dst, uint32_t &at, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t j = 0; j < (uint32_t)NW; j++) {
+        const uint32_t k = lane + 64 * j;
+        if (64 * j < n) {
+            const uint32_t sym = k < n ? src[k] : 0u;
+            const bool keep = k < n && !mtf_in_set<NW>(skip, sym);
+            const uint64_t m = __ballot(keep);
+            if (keep) dst[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)sym;
+            at += (uint32_t)__popcll(m);
         }
     }
 }
 
-// (a) recency list of every group of MTF_GROUP chunks (one lane per group); (b) the MTF list at my chunk start:
-// earlier chunks of my group, then earlier groups, most recent first, then the never-seen symbols in id order.
-// recs: the chunks' recency lists (LDS, or global memory for large alphabets), lists: the working lists (LDS).
+// The MTF list at the start of every chunk -- the symbols by their most recent use before the chunk, then the never-seen
+// ones in id order -- from the chunks' recency lists (recs: LDS, or global memory for large alphabets) and symbol sets
+// (masks, global memory) into the working lists (LDS).
+// Rounds 1-3 let every lane walk back through the lists of the chunks before its own (two levels: 32 chunks, groups of
+// 32) until it had seen every symbol.  On source code -- a hundred symbols, a few of them rare, so no walk ends early
+// and every lane of a wave stops somewhere else -- that was 0.8 ms per block, as much as the ranking itself.  Now a
+// WAVE owns 64 consecutive chunks and every step is one parallel pass over a list (<= 64 * NW entries, entry k on lane
+// k & 63):
+//   A. the recency list of its 64 chunks together: from the last chunk backwards, append what is new (chunks whose
+//      set brings nothing new are skipped after one AND);
+//   B. the list at its first chunk: the group lists of the waves before it, most recent first, the same way, then
+//      the never-seen symbols;
+//   C. chunk after chunk: list(c + 1) = recency list of chunk c, then list(c) without the symbols of chunk c.
 template <int NW, typename RecPtr>
 __device__ __forceinline__ void mtf_start_lists(uint32_t tid, uint32_t nch_used, uint32_t n_in_use, uint32_t stride,
-                                                bool have_chunk, RecPtr recs, uint8_t *lists)
+                                                RecPtr recs, const uint64_t *masks, uint8_t *lists,
+                                                unsigned long long *dbg, unsigned long long &t_last)
 {
-    if (tid * MTF_GROUP < nch_used) {
-        SeenSet<NW> seen;
-        seen.clear();
-        uint32_t cnt = 0;
-        uint8_t *sup = m_super + tid * 264;
-        const uint32_t g_lo = tid * MTF_GROUP;
-        const uint32_t g_hi = g_lo + MTF_GROUP < nch_used ? g_lo + MTF_GROUP : nch_used;
-        for (uint32_t c = g_hi; c > g_lo && cnt < n_in_use;) {
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t lo = wave * 64;
+    const uint32_t hi = lo + 64 < nch_used ? lo + 64 : nch_used;
+    // lane l keeps what the steps need to know about chunk lo + l: its set and the length of its recency list
+    uint64_t my_mask[NW];
+    uint32_t my_rc = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) my_mask[i] = 0;
+    if (lo + lane < nch_used) {
+#pragma unroll
+        for (int i = 0; i < NW; i++) my_mask[i] = masks[(size_t)(lo + lane) * NW + i];
+        my_rc = m_reccnt[lo + lane];
+    }
+    if (lo < nch_used) {
+        uint64_t seen[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) seen[i] = 0;
+        uint32_t gc = 0;
+        uint8_t *grp = m_super + wave * 264;
+        for (uint32_t c = hi; c > lo && gc < n_in_use;) {
             c--;
-            mtf_take_new<NW>(recs + c * stride, m_reccnt[c], seen, sup, cnt);
+            uint64_t mk[NW];
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < NW; i++) {
+                mk[i] = __shfl(my_mask[i], (int)(c - lo));
+                any = any || (mk[i] & ~seen[i]) != 0;
+            }
+            const uint32_t rc = (uint32_t)__shfl((int)my_rc, (int)(c - lo));
+            if (any) {
+                mtf_append_new<NW>(recs + c * stride, rc, seen, grp, gc, lane);
+#pragma unroll
+                for (int i = 0; i < NW; i++) seen[i] |= mk[i];
+            }
         }
-        m_supercnt[tid] = (uint16_t)cnt;
+        if (lane == 0) {
+            m_supercnt[wave] = (uint16_t)gc;
+#pragma unroll
+            for (int i = 0; i < NW; i++) m_supermask[wave * 4 + i] = seen[i];
+        }
     }
     __syncthreads();
-    if (have_chunk) {
-        SeenSet<NW> seen;
-        seen.clear();
+    if (dbg && tid == 0) {                                      // (diagnostic phase timer: step A)
+        const unsigned long long now_ = wall_clock64();
+        atomicAdd(&dbg[37], now_ - t_last);
+        t_last = now_;
+    }
+    if (lo < nch_used) {
+        uint64_t seen[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) seen[i] = 0;
         uint32_t cnt = 0;
-        uint8_t *lst = lists + tid * stride;
-        const uint32_t g = tid / MTF_GROUP;
-        for (uint32_t c = tid; c > g * MTF_GROUP && cnt < n_in_use;) {
-            c--;
-            mtf_take_new<NW>(recs + c * stride, m_reccnt[c], seen, lst, cnt);
-        }
-        for (uint32_t gg = g; gg > 0 && cnt < n_in_use;) {
-            gg--;
-            mtf_take_new<NW>(m_super + gg * 264, m_supercnt[gg], seen, lst, cnt);
+        uint8_t *lst = lists + lo * stride;
+        for (uint32_t g = wave; g > 0 && cnt < n_in_use;) {
+            g--;
+            uint64_t mk[NW];
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < NW; i++) {
+                mk[i] = m_supermask[g * 4 + i];
+                any = any || (mk[i] & ~seen[i]) != 0;
+            }
+            if (any) {
+                mtf_append_new<NW>((const uint8_t *)m_super + g * 264, (uint32_t)m_supercnt[g], seen, lst, cnt, lane);
+#pragma unroll
+                for (int i = 0; i < NW; i++) seen[i] |= mk[i];
+            }
         }
         // symbols never seen so far keep the initial (ascending) order
-        for (uint32_t s = 0; s < n_in_use && cnt < n_in_use; s++)
-            if (!seen.test(s)) lst[cnt++] = (uint8_t)s;
-        for (; cnt < stride; cnt++) lst[cnt] = 0xff;           // padding never matches before a real entry
+#pragma unroll
+        for (uint32_t j = 0; j < (uint32_t)NW; j++) {
+            const uint32_t sy = lane + 64 * j;
+            const bool keep = sy < n_in_use && !mtf_in_set<NW>(seen, sy);
+            const uint64_t m = __ballot(keep);
+            if (keep) lst[cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)sy;
+            cnt += (uint32_t)__popcll(m);
+        }
+        for (uint32_t k = n_in_use + lane; k < stride; k += 64) lst[k] = 0xff;        // padding never matches before a real entry
+        lds_order();
+        // ---- C.  (the recency list of the next step is loaded while this one is merged)
+        uint32_t rnext[NW];
+        {
+            const uint32_t rc = (uint32_t)__shfl((int)my_rc, 0);
+#pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)NW; j++) rnext[j] = lane + 64 * j < rc ? recs[lo * stride + lane + 64 * j] : 0u;
+        }
+        for (uint32_t c = lo; c + 1 < hi; c++) {
+            const uint8_t *cur = lists + c * stride;
+            uint8_t *nxt = lists + (c + 1) * stride;
+            uint64_t mk[NW];
+#pragma unroll
+            for (int i = 0; i < NW; i++) mk[i] = __shfl(my_mask[i], (int)(c - lo));
+            const uint32_t rc = (uint32_t)__shfl((int)my_rc, (int)(c - lo));
+            const uint32_t rc1 = (uint32_t)__shfl((int)my_rc, (int)(c + 1 - lo));
+            uint32_t rcur[NW];
+#pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)NW; j++) {
+                rcur[j] = rnext[j];
+                rnext[j] = c + 2 < hi && lane + 64 * j < rc1 ? recs[(c + 1) * stride + lane + 64 * j] : 0u;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)NW; j++)
+                if (lane + 64 * j < rc) nxt[lane + 64 * j] = (uint8_t)rcur[j];
+            uint32_t at = rc;
+            mtf_append_new<NW>(cur, n_in_use, mk, nxt, at, lane);
+            for (uint32_t k = n_in_use + lane; k < stride; k += 64) nxt[k] = 0xff;
+            lds_order();
+        }
     }
 }
 
@@ -325,6 +428,7 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         // zero-run pass -- and the working lists get the whole pool: twice the lanes.
         const bool big = n_in_use > 64;
         uint8_t *grec = reinterpret_cast<uint8_t *>(V);            // [nch][stride] (<= 1,024 x 264 B of the 1.8 MB slab)
+        uint64_t *gmask = reinterpret_cast<uint64_t *>(grec + MTF_NT * 264);        // [nch][NW] the symbols of every chunk
         uint8_t *lists = big ? m_pool : m_list;
         uint32_t nch = (big ? 2 * MTF_LIST_BYTES : MTF_LIST_BYTES) / stride;
         if (nch > MTF_NT) nch = MTF_NT;
@@ -337,17 +441,17 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
 
         // ---- 3. recency list of my chunk: distinct symbols by last occurrence, most recent first
         if (have_chunk) {
-            if (n_in_use <= 64) mtf_recency<1>(H, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid]);
-            else if (n_in_use <= 128) mtf_recency<2>(H, c_lo, c_hi, n_in_use, grec + tid * stride, &m_reccnt[tid]);
-            else mtf_recency<4>(H, c_lo, c_hi, n_in_use, grec + tid * stride, &m_reccnt[tid]);
+            if (n_in_use <= 64) mtf_recency<1>(H, c_lo, c_hi, n_in_use, m_rec + tid * stride, &m_reccnt[tid], gmask + tid);
+            else if (n_in_use <= 128) mtf_recency<2>(H, c_lo, c_hi, n_in_use, grec + tid * stride, &m_reccnt[tid], gmask + tid * 2);
+            else mtf_recency<4>(H, c_lo, c_hi, n_in_use, grec + tid * stride, &m_reccnt[tid], gmask + tid * 4);
         }
         __syncthreads();                 // (also orders the global recency lists: all waves of a workgroup share the unit's L1)
         MTF_STAMP(33);
 
         // ---- 4. MTF list at every chunk start (two-level walk over the recency lists)
-        if (n_in_use <= 64) mtf_start_lists<1>(tid, nch_used, n_in_use, stride, have_chunk, (const uint8_t *)m_rec, lists);
-        else if (n_in_use <= 128) mtf_start_lists<2>(tid, nch_used, n_in_use, stride, have_chunk, (const uint8_t *)grec, lists);
-        else mtf_start_lists<4>(tid, nch_used, n_in_use, stride, have_chunk, (const uint8_t *)grec, lists);
+        if (n_in_use <= 64) mtf_start_lists<1>(tid, nch_used, n_in_use, stride, (const uint8_t *)m_rec, gmask, lists, B.dbg, t_last);
+        else if (n_in_use <= 128) mtf_start_lists<2>(tid, nch_used, n_in_use, stride, (const uint8_t *)grec, gmask, lists, B.dbg, t_last);
+        else mtf_start_lists<4>(tid, nch_used, n_in_use, stride, (const uint8_t *)grec, gmask, lists, B.dbg, t_last);
         __syncthreads();
         MTF_STAMP(34);
 
