@@ -462,6 +462,7 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
             Be.ctr_bwt = BZX_CTR_REDO_FETCH;
             Be.redo_once = 1;
             bzx_launch_bwt(Be, n_early, ctx->aux);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
         }
         B.bsort_mode = 0;
         bzx_launch_bsort(B, bzx_bsort_blocks_per_cu() * ncu, ctx->stream);
@@ -471,23 +472,12 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         // buckets and enters their ranks into the block's rank array (inside the general sorter's slots from rk_slot0
         // on), prefix-doubling rounds over the open buckets finish the leftover groups -- any workgroup on any bucket,
         // each launch exits at once when nothing is open.  Then the general sorter takes what is left: refused blocks
-        // beyond the early launch's 32, and resume blocks still open after the rank rounds (periodic blocks, more
-        // resume blocks than rank arrays).
+        // beyond the early launch's 32, and resume blocks still open after the rank rounds (periodic blocks, blocks
+        // with an oversized group and the buckets that read its coarse ranks, stress builds: blocks without rank arrays).
         BzxBatch Bf = B;
         Bf.bsort_mode = 1;
         bzx_launch_bsort(Bf, bzx_bsort_blocks_per_cu() * ncu, ctx->stream);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_b3, ctx->stream));
-        if (early) {
-            // blocks with an oversized bin (no rank array): their leftover groups go to the general sorter's
-            // prefix-doubling rounds, on the side stream again, while the rank rounds finish all other resume blocks
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_b3, 0));
-            BzxBatch Be = B;
-            Be.redo = 2;
-            Be.ctr_bwt = BZX_CTR_RESUME_FETCH2;
-            Be.redo_once = 2;
-            bzx_launch_bwt(Be, n_early, ctx->aux);
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
-        }
         bzx_launch_brank(B, bzx_bsort_blocks_per_cu() * ncu, ctx->stream);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_b4, ctx->stream));
         if (early) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));

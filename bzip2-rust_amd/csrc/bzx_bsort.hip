@@ -258,24 +258,37 @@ __device__ __forceinline__ bool bucket_emit(const BzxBatch &B, uint32_t blk, uin
     return b_bcast[4] == 0;
 }
 
-// An oversized bin the split gives up on (depth or split limit: thousands of rotations sharing a long prefix) is left
-// as ONE group of tied ranks in the resume format ([group start:1 @32 | rotation:20], see the sort kernel), and the
-// block joins the resume blocks WITHOUT a rank array: every other bucket is sorted as usual, but the leftover groups
-// of the whole block are finished by the general sorter's prefix-doubling rounds -- the bucket-level rank rounds
-// cannot take part, because doubling the depth is only valid when every tied group of the block is refined in every
-// round, and this one is too big for them.  rec_a / rec_b: the block's slabs.
+// Rank arrays (rank of every rotation, uint32[BZX_MAX_N]) of the block in slab k: TWO per block -- a rank round reads
+// one and writes the other, so no rank changes under a reader (see the rank rounds).  nullptr: none (stress builds).
+__device__ __forceinline__ uint32_t *rank_array(const BzxBatch &B, uint32_t k, uint32_t which)
+{
+    if (k >= B.rk_blocks) return nullptr;
+    return B.isa2 + ((size_t)k * 2 + which) * BZX_MAX_N;
+}
+
+// An oversized bin the split gives up on (depth or split limit: thousands of rotations sharing a long prefix -- table
+// borders, padding patterns) is left as ONE group of tied ranks in the resume format ([group start:1 @32 | rotation:20],
+// see the sort kernel) and the block joins the resume blocks.  The rank rounds cannot refine such a group (it does not
+// fit a workgroup), and doubling the depth is only valid where every rank read is as deep as the round assumes: so the
+// members' entries in both rank arrays carry RK_COARSE, a bucket that reads a coarse rank leaves the rounds with its own
+// tied ranks marked coarse too (see the rank rounds), and the general sorter finishes whatever is left of the block --
+// this group, those buckets -- afterwards.  (Until round 3 such a block went to the general sorter with ALL its tied
+// ranks, half a block of them in real files: 15-50 ms by one workgroup, the tail of the whole batch.)
+// rec_a / rec_b: the block's slabs.
 __device__ __forceinline__ void emit_giant(const BzxBatch &B, uint32_t blk, uint64_t *rec_a, const uint64_t *rec_b,
                                            uint32_t st, uint32_t cnt, uint32_t depth, uint32_t bits)
 {
     const uint32_t tid = threadIdx.x, base = st & 0x7fffffffu;
     const uint64_t *src = ((st >> 31) ? rec_b : rec_a) + base;      // (may be the very range written below)
+    uint32_t *__restrict__ isa0 = rank_array(B, (uint32_t)BZX_SLAB(B, blk), 0), *__restrict__ isa1 = rank_array(B, (uint32_t)BZX_SLAB(B, blk), 1);
     for (uint32_t i = tid; i < cnt; i += BS_NT) {
         const uint64_t r = src[i];
         rec_a[base + i] = (uint64_t)REC_IDX(r) | (i == 0 ? 1ull << 32 : 0ull);
+        if (isa0) isa0[REC_IDX(r)] = isa1[REC_IDX(r)] = base | RK_COARSE;
     }
     if (tid == 0) {
         atomicMin(&B.blk[blk].n_mtf, depth / bits);
-        B.blk[blk].n_selectors = 0xFFFFFFFFu;                      // no rank array
+        atomicAdd(&B.blk[blk].n_groups, 1u);                      // (counts as a bucket that never closes: the block stays in resume state)
         if ((atomicOr(&B.blk[blk].status, BZX_ST_RESUME) & BZX_ST_RESUME) == 0)
             B.resume_list[atomicAdd(&B.counters[BZX_CTR_RESUME], 1u)] = blk;
     }
@@ -1097,14 +1110,6 @@ __device__ __forceinline__ bool initial_sort(uint32_t cnt)
     return true;
 }
 
-// Rank arrays (rank of every rotation, uint32[BZX_MAX_N]) of the k-th block of resume_list: TWO per block -- a rank round
-// reads one and writes the other, so no rank changes under a reader (see the rank rounds).  nullptr: none.
-__device__ __forceinline__ uint32_t *rank_array(const BzxBatch &B, uint32_t k, uint32_t which)
-{
-    if (k == 0xFFFFFFFFu || k >= B.rk_blocks) return nullptr;      // (~0: a block with an oversized bin)
-    return B.isa2 + ((size_t)k * 2 + which) * BZX_MAX_N;
-}
-
 #ifndef SK_WAVES_PER_SIMD
 #define SK_WAVES_PER_SIMD 4             // 128 VGPRs: no spills (at 80 the round loop spills ~40 registers to scratch)
 #endif
@@ -1595,6 +1600,17 @@ __device__ __forceinline__ uint32_t slot_prefix(const uint64_t *keep, uint32_t n
     return total;
 }
 
+__shared__ uint32_t s_stall[2 * BS_FW];       // rank rounds: group starts whose group leaves the rounds (one bit per slot)
+
+// Slot at which the group of slot c starts (slot 0 starts a group).
+__device__ __forceinline__ uint32_t group_start(uint32_t c)
+{
+    uint32_t wi = c >> 6;
+    uint64_t w = s_f[wi] & (~0ull >> (63u - (c & 63u)));
+    while (!w) w = s_f[--wi];
+    return wi * 64 + 63u - (uint32_t)__builtin_clzll(w);
+}
+
 // One rank round of a bucket whose list has at most 64 entries, by ONE wave (slot = lane; no workgroup barrier, no
 // flag words: the group starts are a ballot).  Most buckets of real data give up over a handful of pairs, and a
 // workgroup per such bucket spent its time in barriers: four waves now take four buckets.  Same steps as the
@@ -1607,7 +1623,7 @@ __device__ __forceinline__ void rank_round_wave(const BzxBatch &B, uint32_t i)
     const uint32_t T = bzx_bcast0(mt.T);
     const uint32_t b = bzx_bcast0(mt.blk), start = bzx_bcast0(mt.start);
     const uint32_t rk = bzx_bcast0(mt.rk);
-    const uint32_t *__restrict__ isa_r = rank_array(B, rk, B.rk_h_shift & 1u);
+    uint32_t *__restrict__ isa_r = rank_array(B, rk, B.rk_h_shift & 1u);
     uint32_t *__restrict__ isa_w = rank_array(B, rk, (B.rk_h_shift & 1u) ^ 1u);
     const uint32_t n = bzx_bcast0(mt.n);
     const uint64_t h64 = (uint64_t)bzx_bcast0(mt.h0) << B.rk_h_shift;
@@ -1625,10 +1641,18 @@ __device__ __forceinline__ void rank_round_wave(const BzxBatch &B, uint32_t i)
     if (single) isa_w[rot] = start + pc;                                   // settled last round: the other array's copy
     uint32_t x = rot + h;
     if (x >= n) x -= n;
-    const uint64_t key = tied ? ((uint64_t)isa_r[x] << 8) | lane : 0ull;     // (rank, then slot: a stable order)
+    const uint32_t ahead = tied ? isa_r[x] : 0u;
     const uint32_t gs = 63u - (uint32_t)__builtin_clzll((F & (~0ull >> (63u - lane))) | 1ull);
     const uint64_t above = lane == 63 ? 0ull : F >> (lane + 1);
     const uint32_t ge = above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : 64u;
+    // A group in which a rank read is coarse cannot be ordered by this round, nor by a later one (its ranks would be
+    // shallower than the round assumes): it leaves the rounds as it is.  Its members' entries in BOTH rank arrays get
+    // RK_COARSE (same rank value as before: a reader of the array being read sees the old entry or the marked one, and
+    // either is right for it), their rows go out in the resume format, they drop out of the list, and the block keeps
+    // one more open "bucket" than it will ever close: the general sorter finishes it.
+    const uint64_t C = __ballot(ahead >> 31);
+    const bool stall = tied && (C & (~0ull >> (64u - ge)) & (~0ull << gs)) != 0;
+    const uint64_t key = tied ? ((uint64_t)(stall ? 0u : ahead) << 8) | lane : 0ull;     // (rank, then slot: a stable order)
     lds_order();
     wk[lane] = key;
     lds_order();
@@ -1653,7 +1677,11 @@ __device__ __forceinline__ void rank_round_wave(const BzxBatch &B, uint32_t i)
     const uint32_t p_head = (uint32_t)__shfl((int)pc, (int)hc);
     const bool f0n = (Fn >> lane) & 1ull, f1n = lane == 63 ? true : (Fn >> (lane + 1)) & 1ull;
     uint32_t out = 0;
-    if (tied) {
+    if (stall) {
+        isa_r[rot_n] = isa_w[rot_n] = (start + p_head) | RK_COARSE;
+        uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
+        sax[pc] = (uint64_t)rot_n | ((uint64_t)f0n << 32);
+    } else if (tied) {
         isa_w[rot_n] = start + p_head;
         out = pc | ((uint32_t)f0n << 11) | (rot_n << 12);
         uint64_t *__restrict__ sax = B.rec_a + BZX_SLAB(B, b) * BZX_MAX_N + start;
@@ -1667,11 +1695,12 @@ __device__ __forceinline__ void rank_round_wave(const BzxBatch &B, uint32_t i)
             sax[pc] = (uint64_t)rot_n | ((uint64_t)f0n << 32);
         }
     }
-    const uint64_t keep = __ballot(tied);
-    if (tied) cl[(uint32_t)__popcll(keep & ((1ull << lane) - 1ull))] = out;
+    const uint64_t keep = __ballot(tied && !stall);
+    if (tied && !stall) cl[(uint32_t)__popcll(keep & ((1ull << lane) - 1ull))] = out;
     if (lane == 0) {
         const uint32_t Tn = (uint32_t)__popcll(keep);
         B.rk_list[B.bk_cap + i] = Tn;
+        if (C) atomicAdd(&B.blk[b].n_groups, 1u);
         if (Tn == 0) {
             B.bk_list[bi].dbits |= 0x80000000u;
             atomicSub(&B.counters[BZX_CTR_RK_OPEN], 1u);
@@ -1720,7 +1749,7 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
         const uint32_t T = uni(mt.T);
         const uint32_t b = uni(mt.blk), start = uni(mt.start);
         const uint32_t rk = uni(mt.rk);
-        const uint32_t *__restrict__ isa_r = rank_array(B, rk, B.rk_h_shift & 1u);
+        uint32_t *__restrict__ isa_r = rank_array(B, rk, B.rk_h_shift & 1u);
         uint32_t *__restrict__ isa_w = rank_array(B, rk, (B.rk_h_shift & 1u) ^ 1u);
         const uint32_t n = uni(mt.n);
         const uint64_t h64 = (uint64_t)uni(mt.h0) << B.rk_h_shift;
@@ -1778,6 +1807,37 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++)
             if ((zmask >> j) & 1u) isa_w[ent[j] >> 12] = start + (ent[j] & 2047u);
+        // groups in which a rank read is coarse leave the rounds (see rank_round_wave): the group start of every such
+        // read is marked, then every tied slot looks its own group start up
+        uint32_t smask = 0;
+        {
+            uint32_t coarse = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) coarse |= g[j] >> 31;
+            if (__syncthreads_or((int)coarse)) {
+                if (tid < 2 * BS_FW) s_stall[tid] = 0;
+                __syncthreads();
+#pragma unroll
+                for (uint32_t j = 0; j < BS_E; j++) {
+                    if (g[j] >> 31) {
+                        const uint32_t hc = group_start(j * SK_NT + tid);
+                        atomicOr(&s_stall[hc >> 5], 1u << (hc & 31u));
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (uint32_t j = 0; j < BS_E; j++) {
+                    if ((tmask >> j) & 1u) {
+                        const uint32_t hc = group_start(j * SK_NT + tid);
+                        if ((s_stall[hc >> 5] >> (hc & 31u)) & 1u) {
+                            smask |= 1u << j;
+                            g[j] = 0;                                  // (equal keys: the group stays as it is)
+                        }
+                    }
+                }
+                if (tid == 0) atomicAdd(&B.blk[b].n_groups, 1u);       // (never closed: the block stays in resume state)
+            }
+        }
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++) {
             if ((hmask >> j) & 1u) {
@@ -1892,15 +1952,20 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
                 uint64_t w = s_f[wi] & (~0ull >> (63u - (c & 63u)));
                 while (!w) w = s_f[--wi];                          // (slot 0 starts a group)
                 const uint32_t hc = wi * 64 + 63u - (uint32_t)__builtin_clzll(w);
-                isa_w[rot] = start + LIST(0, hc);
-                out[j] = pc | (f0 << 11) | (rot << 12);
-                kp = true;
-                if (f0 && f1) {                                    // settled
-                    L[pc] = Tx[rot ? rot - 1 : n - 1];
-                    sax[pc] = (uint64_t)rot | (1ull << 32);
-                    if (rot == 0) B.blk[b].orig_ptr = start + pc;
-                } else if (B.rk_last) {
-                    sax[pc] = (uint64_t)rot | ((uint64_t)f0 << 32);   // (still tied after the last round: general sorter)
+                if ((smask >> j) & 1u) {                           // leaves the rounds, coarse
+                    isa_r[rot] = isa_w[rot] = (start + LIST(0, hc)) | RK_COARSE;
+                    sax[pc] = (uint64_t)rot | ((uint64_t)f0 << 32);
+                } else {
+                    isa_w[rot] = start + LIST(0, hc);
+                    out[j] = pc | (f0 << 11) | (rot << 12);
+                    kp = true;
+                    if (f0 && f1) {                                // settled
+                        L[pc] = Tx[rot ? rot - 1 : n - 1];
+                        sax[pc] = (uint64_t)rot | (1ull << 32);
+                        if (rot == 0) B.blk[b].orig_ptr = start + pc;
+                    } else if (B.rk_last) {
+                        sax[pc] = (uint64_t)rot | ((uint64_t)f0 << 32);   // (still tied after the last round: general sorter)
+                    }
                 }
             }
             keep[j] = __ballot(kp);
@@ -1922,10 +1987,6 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
     }
     DIAG_FLUSH();
 }
-
-#ifndef RK_ROUNDS
-#define RK_ROUNDS 15                    // depths h0 .. h0 << 13 (enough for give-up depths from 55 symbols on) + one round in
-#endif                                  // which the ranks settled last only leave their lists
 
 void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream)
 {

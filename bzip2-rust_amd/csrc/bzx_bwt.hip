@@ -1030,7 +1030,6 @@ __device__ __forceinline__ void bwt_body(const BzxBatch &B)
         const uint32_t b = B.redo == 2 ? B.resume_list[j_] : B.redo ? B.redo_list[j_] : B.blk_first + j_ * B.blk_step;
         if (B.redo == 2 && !(B.blk[b].status & BZX_ST_RESUME)) continue;      // finished by the bucket sorter's rank rounds
                                                                                // (or by this kernel's early launch)
-        if (B.redo == 2 && B.redo_once == 2 && B.blk[b].n_selectors != 0xFFFFFFFFu) continue;   // early launch: see bzx_device.h
         if (B.redo == 2 && tid == 0) atomicAdd(&B.counters[BZX_CTR_RESUME_LEFT], 1u);
 
         const uint32_t n = B.blk[b].n;
@@ -1162,7 +1161,21 @@ __device__ __forceinline__ void bwt_body(const BzxBatch &B)
 
         // ---- RANK rounds (deep repeats): build ISA once, then prefix doubling on ranks
         if (m > 0 && depth < n) {
-            isa_build(ws.sa, ws.isa, ub, n);                                        // resolved rotations: final rank
+            // resolved rotations: final rank.  A block that went through the bucket sorter's rank rounds has them in
+            // its rank arrays already (the array the block's last round wrote is complete: a rank settled in a round
+            // is copied to the other array in the next); a scatter of n ranks by one workgroup took 5 ms.
+            const uint32_t *isa_src = nullptr;
+            if (B.redo == 2 && B.blk[b].n_selectors < B.rk_blocks) {
+                uint32_t r = 0;
+                while (r < RK_ROUNDS && ((uint64_t)depth << r) < n) r++;             // rounds the block took part in
+                isa_src = B.isa2 + ((size_t)B.blk[b].n_selectors * 2 + (r & 1u)) * BZX_MAX_N;
+            }
+            if (isa_src) {
+                for (uint32_t k = tid; k < n; k += SORT_NT) ws.isa[k] = isa_src[k] & ~RK_COARSE;
+                __syncthreads();
+            } else {
+                isa_build(ws.sa, ws.isa, ub, n);
+            }
             for (uint32_t k = tid; k < m; k += SORT_NT) {                           // unresolved: group start
                 const uint64_t rec = ua[k];
                 const uint32_t sa = (uint32_t)(rec >> TXT_SA_SHIFT) & 0xFFFFFu;

@@ -21,6 +21,12 @@
 #define BZX_ST_PERIODIC 1u         // block is u^k, k>1: identical rotations exist
 #define BZX_ST_REDO 2u             // the split kernel handed the block to the general sorter, to be sorted from scratch
 #define BZX_ST_RESUME 4u           // a bucket gave up (deep repeats): the general sorter finishes the leftover groups
+// Rank rounds of the bucket sorter (bzx_bsort.hip): round r compares ranks (give-up depth << r) symbols ahead.
+#ifndef RK_ROUNDS
+#define RK_ROUNDS 15               // depths h0 .. h0 << 13 (enough for give-up depths from 55 symbols on) + one round in
+#endif                             // which the ranks settled last only leave their lists
+#define RK_COARSE 0x80000000u      // rank array entry: this rank is NOT refined by the rank rounds (member of an oversized
+                                   // group, or of a bucket that had to read such a rank): valid at the give-up depth only
 #define BZX_PK_STRIDE 900352u      // per-block stride of the packed blocks (bzx_pack.h): (n + 207 symbols) * 8 bits max
 #ifndef BZX_BK_PER_BLOCK
 #define BZX_BK_PER_BLOCK 2048u     // bucket work items reserved per block (average over the blocks of a batch)
@@ -47,7 +53,6 @@
 #define BZX_CTR_RK_OPEN 33          // ... of which still open
 #define BZX_CTR_RK_FETCH 64         // [64..191] one work-fetch counter per launch of the rank-round kernels
 #define BZX_N_COUNTERS 192
-#define BZX_CTR_RESUME_FETCH2 38     // ... by its early launch (blocks with an oversized bin)
 #define BZX_CTR_RESUME_LEFT 34      // resume blocks the general sorter still had to finish
 #define BZX_CTR_STAT0 16           // [16..31] diagnostics of the bucket sorter (rounds, leftovers, ...)
 
@@ -72,7 +77,7 @@ struct BzxBlock {
     uint32_t n_mtf;         // MTF/RLE2: number of symbols incl. EOB
     uint32_t n_in_use;      // distinct byte values in the block
     uint32_t n_groups;      // Huffman: coding tables 2..6   (bucket sorter, until then: buckets of the block still open)
-    uint32_t n_selectors;   // ceil(n_mtf / 50)              (bucket sorter, until then: index of the block in resume_list)
+    uint32_t n_selectors;   // ceil(n_mtf / 50)              (bucket sorter, until then: the block's pair of rank arrays)
     uint64_t bits;          // size of the block image in bits (header .. last payload bit)
     uint64_t out_bit;       // bit position of the block image in the output buffer
     uint32_t sec_bits[4];   // [0] selectors, [1] coding tables, [2] payload, [3] symbol map
@@ -143,8 +148,7 @@ struct BzxBatch {
     uint32_t bsort_mode;    // bucket sort kernel: 0 = sort; 1 = fill pass (write the order of the finished buckets of BZX_ST_RESUME blocks)
     uint32_t n_slots;
     uint32_t slot_base;     // general sorter: workgroup g works in sort slot slot_base + g
-    uint32_t redo_once;     // general sorter, early launches beside the bucket sorter: 1 = redo mode, every workgroup takes at most one
-                            // block; 2 = resume mode, only the blocks without a rank array (oversized bin)
+    uint32_t redo_once;     // general sorter, early launch beside the bucket sorter: 1 = redo mode, every workgroup takes at most one block
     uint32_t rk_slot0;      // rank rounds: first sort slot that holds rank arrays
     uint32_t dbg_stop;       // diagnostics only: leave the BWT kernel after phase k (0 = run everything)
     unsigned long long *dbg; // optional [64] phase timers (100 MHz ticks), null in production

@@ -57,7 +57,8 @@ def run(name, data, ref="oracle"):
     want = o.compress_mt(data, 9) if ref == "oracle" else bz2.compress(data, 9)
     dr = time.time() - t
     print(f"{name:12s} raw={len(data):10d} ratio={len(out)/max(1,len(data)):.3f} blocks={st.nblk:4d} buckets={st.n_buckets:6d} "
-          f"redo={st.n_redo:3d} periodic={st.n_periodic} device {len(data)/1e6/(st.ms_total/1e3):8.1f} MB/s "
+          f"redo={st.n_redo:3d} periodic={st.n_periodic} host-to-host {len(data)/1e6/(st.ms_total/1e3):7.1f} MB/s, stage kernels "
+          f"{len(data)/1e6/((st.ms_split+st.ms_bwt+st.ms_mtf+st.ms_huffman+st.ms_emit)/1e3):7.1f} MB/s "
           f"ms split/bwt[split,sort,general]/mtf/huf/emit={st.ms_split:.2f}/{st.ms_bwt:.2f}[{st.ms_bwt_split:.2f},{st.ms_bwt_sort:.2f},"
           f"{st.ms_bwt_general:.2f} (rank {st.ms_bwt_rank:.2f}, gave-up {st.n_open_buckets} left {st.n_open_left} blocks-left {st.n_resume_left} from-scratch {st.n_from_scratch})]/{st.ms_mtf:.2f}/{st.ms_huffman:.2f}/{st.ms_emit:.2f} ref {dr:.1f}s parity={'OK' if want == out else 'MISMATCH'}",
           flush=True)
