@@ -1518,9 +1518,11 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bfill_kernel(Bzx
 // files, licence headers, tables in binaries).  Its order and group starts were written back for ALL its ranks (the
 // general sorter's fall-back) and once more, for the TIED ranks only, as a compact list of 4-byte entries; the fill
 // pass entered the ranks of the finished buckets of the block into the block's two rank arrays.  From there on the
-// leftover groups -- all inside one bucket -- are refined by the ranks of the rotations h symbols ahead (h = the
-// block's smallest give-up depth, doubling every round): the refinement round of the sort kernel with
-// ISA[(rotation + h) mod n] in place of the next 50 key bits, on the compact list.
+// leftover groups -- all inside one bucket -- are refined by the ranks of the rotations h and 2h symbols ahead (h = the
+// block's smallest give-up depth, times three every round: two gathers per tied rank buy a third fewer visits of it,
+// and the fixed cost of a bucket's round -- list in, barriers, list out -- is what the rounds are made of): the
+// refinement round of the sort kernel with [ISA[(rotation + h) mod n], ISA[(rotation + 2h) mod n]] in place of the next
+// 50 key bits, on the compact list.
 //   before      : a bucket that gives up (sort kernel) enters the group-head rank of each of its ranks into rank array
 //                 0, and the ranks that are alone in their group into array 1 too.
 //   round r     : ONE launch.  A bucket loads its list, gathers from rank array r & 1, orders its groups, enters the
@@ -1626,7 +1628,7 @@ __device__ __forceinline__ void rank_round_wave(const BzxBatch &B, uint32_t i)
     uint32_t *__restrict__ isa_r = rank_array(B, rk, B.rk_h_shift & 1u);
     uint32_t *__restrict__ isa_w = rank_array(B, rk, (B.rk_h_shift & 1u) ^ 1u);
     const uint32_t n = bzx_bcast0(mt.n);
-    const uint64_t h64 = (uint64_t)bzx_bcast0(mt.h0) << B.rk_h_shift;
+    const uint64_t h64 = (uint64_t)bzx_bcast0(mt.h0) * B.rk_h_mul;
     if (!isa_r || h64 >= n) return;
     const uint32_t h = (uint32_t)h64;
     uint32_t *__restrict__ cl = reinterpret_cast<uint32_t *>(B.rec_b + BZX_SLAB(B, b) * BZX_MAX_N + start);
@@ -1641,7 +1643,9 @@ __device__ __forceinline__ void rank_round_wave(const BzxBatch &B, uint32_t i)
     if (single) isa_w[rot] = start + pc;                                   // settled last round: the other array's copy
     uint32_t x = rot + h;
     if (x >= n) x -= n;
-    const uint32_t ahead = tied ? isa_r[x] : 0u;
+    uint32_t x2 = x + h;
+    if (x2 >= n) x2 -= n;
+    const uint32_t ahead = tied ? isa_r[x] : 0u, ahead2 = tied ? isa_r[x2] : 0u;      // ranks h and 2h symbols ahead
     const uint32_t gs = 63u - (uint32_t)__builtin_clzll((F & (~0ull >> (63u - lane))) | 1ull);
     const uint64_t above = lane == 63 ? 0ull : F >> (lane + 1);
     const uint32_t ge = above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : 64u;
@@ -1650,9 +1654,9 @@ __device__ __forceinline__ void rank_round_wave(const BzxBatch &B, uint32_t i)
     // RK_COARSE (same rank value as before: a reader of the array being read sees the old entry or the marked one, and
     // either is right for it), their rows go out in the resume format, they drop out of the list, and the block keeps
     // one more open "bucket" than it will ever close: the general sorter finishes it.
-    const uint64_t C = __ballot(ahead >> 31);
+    const uint64_t C = __ballot((ahead | ahead2) >> 31);
     const bool stall = tied && (C & (~0ull >> (64u - ge)) & (~0ull << gs)) != 0;
-    const uint64_t key = tied ? ((uint64_t)(stall ? 0u : ahead) << 8) | lane : 0ull;     // (rank, then slot: a stable order)
+    const uint64_t key = tied ? (stall ? 0ull : ((uint64_t)ahead << 28) | ((uint64_t)ahead2 << 8)) | lane : 0ull;   // (ranks, then slot: a stable order)
     lds_order();
     wk[lane] = key;
     lds_order();
@@ -1752,7 +1756,7 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
         uint32_t *__restrict__ isa_r = rank_array(B, rk, B.rk_h_shift & 1u);
         uint32_t *__restrict__ isa_w = rank_array(B, rk, (B.rk_h_shift & 1u) ^ 1u);
         const uint32_t n = uni(mt.n);
-        const uint64_t h64 = (uint64_t)uni(mt.h0) << B.rk_h_shift;
+        const uint64_t h64 = (uint64_t)uni(mt.h0) * B.rk_h_mul;
         if (!isa_r || h64 >= n) continue;                           // (left to the general sorter: see bzx_launch_brank)
         const uint32_t h = (uint32_t)h64;
         uint32_t *__restrict__ cl = reinterpret_cast<uint32_t *>(B.rec_b + BZX_SLAB(B, b) * BZX_MAX_N + start);
@@ -1801,9 +1805,23 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
                 }
             }
         }
-        uint32_t g[BS_E];
+        uint64_t g[BS_E];                                            // [rank h ahead:20 @44 | rank 2h ahead:20 @24]
+        uint32_t cmask = 0;                                          // slots that read a coarse rank
+        {
+            uint32_t g1[BS_E], g2[BS_E];
 #pragma unroll
-        for (uint32_t j = 0; j < BS_E; j++) g[j] = ((tmask >> j) & 1u) ? isa_r[xa[j]] : 0u;
+            for (uint32_t j = 0; j < BS_E; j++) {
+                uint32_t x2 = xa[j] + h;
+                if (x2 >= n) x2 -= n;
+                g1[j] = ((tmask >> j) & 1u) ? isa_r[xa[j]] : 0u;
+                g2[j] = ((tmask >> j) & 1u) ? isa_r[x2] : 0u;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < BS_E; j++) {
+                cmask |= ((g1[j] | g2[j]) >> 31) << j;
+                g[j] = ((uint64_t)(g1[j] & ~RK_COARSE) << 44) | ((uint64_t)(g2[j] & ~RK_COARSE) << 24);
+            }
+        }
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++)
             if ((zmask >> j) & 1u) isa_w[ent[j] >> 12] = start + (ent[j] & 2047u);
@@ -1811,15 +1829,12 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
         // read is marked, then every tied slot looks its own group start up
         uint32_t smask = 0;
         {
-            uint32_t coarse = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < BS_E; j++) coarse |= g[j] >> 31;
-            if (__syncthreads_or((int)coarse)) {
+            if (__syncthreads_or((int)cmask)) {
                 if (tid < 2 * BS_FW) s_stall[tid] = 0;
                 __syncthreads();
 #pragma unroll
                 for (uint32_t j = 0; j < BS_E; j++) {
-                    if (g[j] >> 31) {
+                    if ((cmask >> j) & 1u) {
                         const uint32_t hc = group_start(j * SK_NT + tid);
                         atomicOr(&s_stall[hc >> 5], 1u << (hc & 31u));
                     }
@@ -1858,7 +1873,7 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
         }
 #pragma unroll
         for (uint32_t j = 0; j < BS_E; j++)
-            if ((tmask >> j) & 1u) s_w[j * SK_NT + tid] = ((uint64_t)g[j] << 44) | (uint64_t)(j * SK_NT + tid);
+            if ((tmask >> j) & 1u) s_w[j * SK_NT + tid] = g[j] | (uint64_t)(j * SK_NT + tid);
         __syncthreads();
         const uint32_t nmed = s_rc[0][1], nlarge = s_rc[0][2];
         if (nmed | nlarge) {
@@ -1997,9 +2012,12 @@ void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream)
         hipLaunchKernelGGL(k, dim3(grid), dim3(SK_NT), 0, stream, R);
     };
     R.rk_h_shift = 0;
+    uint32_t mul = 1;
     R.rk_last = 0;
     for (uint32_t r = 0; r < RK_ROUNDS; r++) {
         R.rk_h_shift = r;
+        R.rk_h_mul = mul;
+        mul = mul < 0x10000000u ? mul * 3u : mul;                    // (saturated: the product with any depth is past every block)
         R.rk_last = r + 1 == RK_ROUNDS;
         go(bzx_brank_round_kernel);
     }

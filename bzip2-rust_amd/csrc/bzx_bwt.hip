@@ -1167,7 +1167,7 @@ __device__ __forceinline__ void bwt_body(const BzxBatch &B)
             const uint32_t *isa_src = nullptr;
             if (B.redo == 2 && B.blk[b].n_selectors < B.rk_blocks) {
                 uint32_t r = 0;
-                while (r < RK_ROUNDS && ((uint64_t)depth << r) < n) r++;             // rounds the block took part in
+                for (uint64_t hh = depth; r < RK_ROUNDS && hh < n; hh *= 3) r++;      // rounds the block took part in
                 isa_src = B.isa2 + ((size_t)B.blk[b].n_selectors * 2 + (r & 1u)) * BZX_MAX_N;
             }
             if (isa_src) {

@@ -21,10 +21,11 @@
 #define BZX_ST_PERIODIC 1u         // block is u^k, k>1: identical rotations exist
 #define BZX_ST_REDO 2u             // the split kernel handed the block to the general sorter, to be sorted from scratch
 #define BZX_ST_RESUME 4u           // a bucket gave up (deep repeats): the general sorter finishes the leftover groups
-// Rank rounds of the bucket sorter (bzx_bsort.hip): round r compares ranks (give-up depth << r) symbols ahead.
+// Rank rounds of the bucket sorter (bzx_bsort.hip): round r compares the ranks h and 2h symbols ahead, h = (give-up
+// depth of the block) * 3^r, and leaves the depth at 3h.
 #ifndef RK_ROUNDS
-#define RK_ROUNDS 15               // depths h0 .. h0 << 13 (enough for give-up depths from 55 symbols on) + one round in
-#endif                             // which the ranks settled last only leave their lists
+#define RK_ROUNDS 11               // depths h0 .. h0 * 3^10 (past every block for give-up depths from 16 symbols on) + one round
+#endif                             // in which the ranks settled last only leave their lists
 #define RK_COARSE 0x80000000u      // rank array entry: this rank is NOT refined by the rank rounds (member of an oversized
                                    // group, or of a bucket that had to read such a rank): valid at the give-up depth only
 #define BZX_PK_STRIDE 900352u      // per-block stride of the packed blocks (bzx_pack.h): (n + 207 symbols) * 8 bits max
@@ -143,7 +144,8 @@ struct BzxBatch {
     uint32_t rk_blocks;     // blocks that get rank arrays (all; stress builds: a few)
     uint32_t rk_fetch;      // rank rounds: this launch's work-fetch counter (index into counters)
     uint32_t rk_last;       // rank rounds: this is the last update launch
-    uint32_t rk_h_shift;    // rank rounds: this round compares ranks h = (give-up depth of the block) << rk_h_shift symbols ahead
+    uint32_t rk_h_shift;    // rank rounds: number of this round (it reads rank array rk_h_shift & 1 and writes the other)
+    uint32_t rk_h_mul;      // rank rounds: 3 ^ round; the round compares the ranks h and 2h symbols ahead, h = (give-up depth of the block) * rk_h_mul
     uint32_t redo;          // general sorter: 1 = sort the blocks of redo_list from scratch; 2 = finish the blocks of resume_list
     uint32_t bsort_mode;    // bucket sort kernel: 0 = sort; 1 = fill pass (write the order of the finished buckets of BZX_ST_RESUME blocks)
     uint32_t n_slots;

@@ -7,7 +7,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 cd /tmp; export TMPDIR=/tmp
 rm -rf $out/tmp_trace
-rocprofv3 --kernel-trace --output-format csv -d $out/tmp_trace -o t -- python3 $root/tests/gpu_probe_bsort.py 128 $which > $out/trace_${which}_probe.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out/tmp_trace -o t -- python3 $root/tests/gpu_probe_bsort.py ${MIB:-128} $which > $out/trace_${which}_probe.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$out/tmp_trace/**/*kernel_trace.csv", recursive=True)[0]
