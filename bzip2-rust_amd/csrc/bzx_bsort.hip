@@ -56,7 +56,8 @@
 #define BS_MAX_SPLITS 1024              // ... and at most this many deeper splits per block: beyond, the general sorter
 #endif
 #ifndef BS_ROUNDS
-#define BS_ROUNDS 5                     // refinement rounds of 50 bits before a bucket gives up (47 + 400 bits)
+#define BS_ROUNDS 4                     // refinement rounds of 50 bits before a bucket gives up: what is still tied then is
+                                        // mostly tied for hundreds of symbols, and the rank rounds get there faster
 #endif
 #ifndef BS_KEYBITS
 #define BS_KEYBITS 32                   // leading bits of the 32-bit record key sorted by the initial LSD passes (a multiple of 8)
