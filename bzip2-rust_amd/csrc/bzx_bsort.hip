@@ -80,7 +80,8 @@ __shared__ unsigned long long s_diag[128];
     if (B.dbg && threadIdx.x == 0) {                                          \
         for (int i_ = 0; i_ < 128; i_++) s_diag[i_] = 0;                      \
         t_last_ = wall_clock64();                                             \
-    }
+    }                                                                         \
+    (void)t_last_;
 #define DIAG_STAMP(slot)                                                      \
     do {                                                                      \
         if (B.dbg && threadIdx.x == 0) {                                      \
@@ -1114,6 +1115,13 @@ __device__ __forceinline__ bool initial_sort(uint32_t cnt)
 #ifndef SK_WAVES_PER_SIMD
 #define SK_WAVES_PER_SIMD 4             // 128 VGPRs: no spills (at 80 the round loop spills ~40 registers to scratch)
 #endif
+// A bucket's records are read once: loaded with the streaming hint they do not push the block's packed text -- which
+// every bucket of the block gathers from -- out of the XCD's L2.
+#ifdef BZX_HIP_EMU
+#define BS_LOAD_REC(p) (*(p))
+#else
+#define BS_LOAD_REC(p) __builtin_nontemporal_load(p)
+#endif
 __device__ __forceinline__ void bsort_body(const BzxBatch &B)
 {
     const uint32_t tid0 = threadIdx.x;
@@ -1139,7 +1147,7 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
         const uint64_t *__restrict__ src = ((it.start >> 31) ? B.rec_b : B.rec_a) + BZX_SLAB(B, it.blk) * BZX_MAX_N +
                                            (it.start & 0x7fffffffu);
 #pragma unroll
-        for (uint32_t j = 0; j < BS_E; j++) nxt[j] = j * SK_NT + tid0 < it.cnt ? src[j * SK_NT + tid0] : ~0ull;
+        for (uint32_t j = 0; j < BS_E; j++) nxt[j] = j * SK_NT + tid0 < it.cnt ? BS_LOAD_REC(src + j * SK_NT + tid0) : ~0ull;
         n_cur = uni(B.blk[it.blk].n);
         st_cur = uni(__atomic_load_n(&B.blk[it.blk].status, __ATOMIC_RELAXED));
     }
@@ -1189,7 +1197,7 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
             const uint64_t *__restrict__ src = ((nit.start >> 31) ? B.rec_b : B.rec_a) + BZX_SLAB(B, nit.blk) * BZX_MAX_N + \
                                                (nit.start & 0x7fffffffu);                                                 \
             const uint32_t tp_ = tid_here();                                                                              \
-            _Pragma("unroll") for (uint32_t j = 0; j < BS_E; j++) nxt[j] = j * SK_NT + tp_ < nit.cnt ? src[j * SK_NT + tp_] : ~0ull; \
+            _Pragma("unroll") for (uint32_t j = 0; j < BS_E; j++) nxt[j] = j * SK_NT + tp_ < nit.cnt ? BS_LOAD_REC(src + j * SK_NT + tp_) : ~0ull; \
             n_nx = B.blk[nit.blk].n;                                   /* (made scalar when it becomes n_cur) */          \
             st_nx = __atomic_load_n(&B.blk[nit.blk].status, __ATOMIC_RELAXED);                                            \
         }

@@ -1018,6 +1018,7 @@ __device__ __attribute__((noinline)) uint32_t resume_load(const uint64_t *__rest
 __device__ __forceinline__ void bwt_body(const BzxBatch &B)
 {
     unsigned long long t_last = 0;
+    (void)t_last;
     const uint32_t tid = threadIdx.x;
     const BzxSortWs ws = B.sort_ws[blockIdx.x + B.slot_base];
 

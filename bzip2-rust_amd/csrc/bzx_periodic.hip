@@ -390,7 +390,6 @@ __device__ static void main_sort(uint32_t *ptr, uint8_t *block, uint16_t *quadra
     __shared__ int32_t running_order[256], copy_start[256], copy_end[256];            // (one wave runs this)
     __shared__ uint8_t big_done[256];
     uint8_t c1;
-    uint16_t s;
 
     // (ftab, ptr, quadrant and the overshoot bytes were set up by main_setup_coop, all lanes)
     for (i = 0; i <= 255; i++) {
