@@ -217,8 +217,9 @@ typedef struct {
     uint32_t n_buckets;         /* bucket work items of the bucket sorter */
     float ms_bwt_split, ms_bwt_sort, ms_bwt_general;   /* parts of ms_bwt: split kernel, bucket sort kernel, everything after it */
     uint32_t n_open_buckets;      /* buckets that gave up after the refinement rounds (deep repeats) */
-    uint32_t n_open_left;         /* ... still open after the rank rounds (left to the general sorter) */
-    uint32_t n_resume_left;       /* blocks the general sorter had to finish */
+    uint32_t n_open_left;         /* ... whose lists of tied ranks the rank rounds did not empty (left to the general sorter) */
+    uint32_t n_resume_left;       /* blocks the general sorter had to finish: such buckets, oversized groups and the groups
+                                     that read their ranks, periodic blocks */
     float ms_bwt_rank;            /* part of ms_bwt_general: rank rounds over the open buckets */
     uint32_t n_from_scratch;      /* blocks the split kernel refused (sorted from scratch by the general sorter) */
     uint32_t n_unsorted;          /* buckets whose optimistic initial sort failed its check (their blocks went to the general sorter): 0 */
