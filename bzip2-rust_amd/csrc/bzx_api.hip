@@ -22,6 +22,7 @@ void bzx_launch_bwt(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_bsplit(const BzxBatch &B, uint32_t grid, uint32_t grid_deep, hipStream_t stream);
 void bzx_launch_bsort(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream);
+void bzx_launch_bgiant(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_pack_max(const BzxBatch &B, uint32_t world, uint64_t *d_out, hipStream_t stream);
 void bzx_launch_periodic(const BzxBatch &B, uint32_t grid, hipStream_t stream);
 void bzx_launch_mtf(const BzxBatch &B, uint32_t grid, hipStream_t stream);
@@ -217,7 +218,7 @@ static int ensure_blocks(bzx_ctx *ctx, uint32_t nblk, uint32_t nslab = 0)
         if ((rc = dev_alloc(ctx, ctx->slabs, &B.bk_list, (size_t)cap * BZX_BK_PER_BLOCK))) return rc;
         B.bk_cap = cap * BZX_BK_PER_BLOCK;
         if ((rc = dev_alloc(ctx, ctx->slabs, &B.rk_list, (size_t)B.bk_cap * 2))) return rc;
-        if ((rc = dev_alloc(ctx, ctx->slabs, &B.deep_list, (size_t)cap * BZX_DEEP_PER_BLOCK * 4 * 2))) return rc;
+        if ((rc = dev_alloc(ctx, ctx->slabs, &B.deep_list, (size_t)cap * BZX_DEEP_PER_BLOCK * 4 * 3))) return rc;
         if ((rc = dev_alloc(ctx, ctx->slabs, &B.isa2, (size_t)cap * 2 * BZX_MAX_N))) return rc;
         B.rk_blocks = cap;
     }
@@ -478,6 +479,7 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         Bf.bsort_mode = 1;
         bzx_launch_bsort(Bf, bzx_bsort_blocks_per_cu() * ncu, ctx->stream);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_b3, ctx->stream));
+        bzx_launch_bgiant(B, ncu, ctx->stream);                      // (a no-op launch unless the split left an oversized group)
         bzx_launch_brank(B, bzx_bsort_blocks_per_cu() * ncu, ctx->stream);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_b4, ctx->stream));
         if (early) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));

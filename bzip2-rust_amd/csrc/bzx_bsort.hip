@@ -260,6 +260,11 @@ __device__ __forceinline__ bool bucket_emit(const BzxBatch &B, uint32_t blk, uin
     return b_bcast[4] == 0;
 }
 
+// Item of the lists of oversized bins (deeper split levels) and of oversized groups (regrouping pass).
+struct BzxDeepItem {
+    uint32_t blk, st, cnt, dbits;           // st: first rank | buffer << 31; dbits: depth in key bits | bits per symbol << 16
+};
+
 // Rank arrays (rank of every rotation, uint32[BZX_MAX_N]) of the block in slab k: TWO per block -- a rank round reads
 // one and writes the other, so no rank changes under a reader (see the rank rounds).  nullptr: none (stress builds).
 __device__ __forceinline__ uint32_t *rank_array(const BzxBatch &B, uint32_t k, uint32_t which)
@@ -283,14 +288,28 @@ __device__ __forceinline__ void emit_giant(const BzxBatch &B, uint32_t blk, uint
     const uint32_t tid = threadIdx.x, base = st & 0x7fffffffu;
     const uint64_t *src = ((st >> 31) ? rec_b : rec_a) + base;      // (may be the very range written below)
     uint32_t *__restrict__ isa0 = rank_array(B, (uint32_t)BZX_SLAB(B, blk), 0), *__restrict__ isa1 = rank_array(B, (uint32_t)BZX_SLAB(B, blk), 1);
+    // listed for the regrouping pass (bzx_brank_giant_kernel) when there is room and the block has rank arrays: then the
+    // members' ranks are plain group-head ranks for now; otherwise they are coarse from the start
+    if (tid == 0) b_bcast[7] = isa0 ? atomicAdd(&B.counters[BZX_CTR_GIANT_CNT], 1u) : 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t at = b_bcast[7];
+    const bool listed = at < B.deep_cap;
     for (uint32_t i = tid; i < cnt; i += BS_NT) {
         const uint64_t r = src[i];
         rec_a[base + i] = (uint64_t)REC_IDX(r) | (i == 0 ? 1ull << 32 : 0ull);
-        if (isa0) isa0[REC_IDX(r)] = isa1[REC_IDX(r)] = base | RK_COARSE;
+        if (isa0) isa0[REC_IDX(r)] = isa1[REC_IDX(r)] = base | (listed ? 0u : RK_COARSE);
     }
     if (tid == 0) {
         atomicMin(&B.blk[blk].n_mtf, depth / bits);
-        atomicAdd(&B.blk[blk].n_groups, 1u);                      // (counts as a bucket that never closes: the block stays in resume state)
+        if (listed) {
+            BzxDeepItem it;
+            it.blk = blk;
+            it.st = base;
+            it.cnt = cnt;
+            it.dbits = 0;
+            reinterpret_cast<BzxDeepItem *>(B.deep_list)[(size_t)2 * B.deep_cap + at] = it;
+        }
+        atomicAdd(&B.blk[blk].n_groups, 1u);                      // (an open "bucket": closed by the regrouping pass if it dissolves the group)
         if ((atomicOr(&B.blk[blk].status, BZX_ST_RESUME) & BZX_ST_RESUME) == 0)
             B.resume_list[atomicAdd(&B.counters[BZX_CTR_RESUME], 1u)] = blk;
     }
@@ -311,9 +330,6 @@ __device__ __forceinline__ void block_redo(const BzxBatch &B, uint32_t b)
 // the entries from `flush_from` on are handed to the list of level `push_lvl` (>= 0) as far as it has room, and a
 // launch of bzx_bsplit_deep_kernel per level deals them to all compute units; past the last level (or a full list)
 // a workgroup finishes its subtree itself.  Returns false when the block has to be sorted from scratch.
-struct BzxDeepItem {
-    uint32_t blk, st, cnt, dbits;           // st: first rank | buffer << 31; dbits: depth in key bits | bits per symbol << 16
-};
 
 __device__ bool deep_process(const BzxBatch &B, uint32_t b, uint32_t j_, uint32_t n, uint32_t bits, const uint8_t *__restrict__ P,
                              uint64_t *__restrict__ rec_a, uint64_t *__restrict__ rec_b, uint32_t done, uint32_t flush_from,
@@ -2010,6 +2026,244 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
         __syncthreads();
     }
     DIAG_FLUSH();
+}
+
+// ---- regrouping pass: the oversized groups the split gave up on, before the rank rounds ------------------------------
+// Such a group (G > BS_C rotations that agree on the split's whole depth) does not fit a workgroup's round, and left
+// alone it poisons its block: its coarse ranks stall every group that reads them, those stall their readers, and in a
+// block that repeats itself the general sorter ends up with half a million tied ranks (python sources: 15 ms for one
+// block).  But round 0 would only SORT the group by the ranks h0 and 2 h0 symbols ahead, and a sort can be started by a
+// partition: the members are dealt into sub-buckets by the rank h0 ahead (4,096 bins over the range the ranks of the
+// members span, adjacent bins merged into buckets of at most BS_C as in the split) -- sub-bucket k holds smaller ranks
+// than sub-bucket k + 1, inside a sub-bucket the order is open.  A sub-bucket that is still too big is dealt again: by
+// the same rank over its narrower span, and once all its members share that rank, by the rank 2 h0 ahead.  Every
+// sub-bucket of 2 .. BS_C members becomes an ordinary item of the rank rounds whose ranks are all tied in ONE group,
+// and round 0 does the rest.  The rank arrays are not touched (round 0 readers still see the old group-head rank of
+// the members, which is as deep as round 0 assumes -- and other workgroups of this launch may be reading it: a reader
+// must not see some members of a group refined and others not; round 0 itself enters the new ranks into the other
+// array).  What cannot be dealt -- more than BS_C members with the same two ranks ahead: padding patterns -- stays one
+// group with coarse ranks as before, and so does a range in which a member would end up alone between two full
+// sub-buckets (its rank would be final, and a final rank has to enter both rank arrays, which only a round can do).
+__global__ __launch_bounds__(BS_NT) void bzx_brank_giant_kernel(BzxBatch B)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t listed = B.counters[BZX_CTR_GIANT_CNT];
+    const uint32_t n_items = listed < B.deep_cap ? listed : B.deep_cap;
+    if (n_items == 0) return;
+    const BzxDeepItem *list = reinterpret_cast<const BzxDeepItem *>(B.deep_list) + (size_t)2 * B.deep_cap;
+    constexpr uint32_t NB = 1u << BS_BIN2;
+    for (;;) {
+        if (tid == 0) b_bcast[0] = atomicAdd(&B.counters[BZX_CTR_GIANT_FETCH], 1u);
+        __syncthreads();
+        const uint32_t gi = b_bcast[0];
+        __syncthreads();
+        if (gi >= n_items) break;
+        const BzxDeepItem d = list[gi];
+        const uint32_t b = d.blk, base = d.st;
+        if (__atomic_load_n(&B.blk[b].status, __ATOMIC_RELAXED) & BZX_ST_REDO) continue;   // sorted from scratch anyway
+        const uint32_t n = B.blk[b].n, h0 = B.blk[b].n_mtf;
+        const size_t sb = BZX_SLAB(B, b);
+        uint32_t *__restrict__ isa0 = rank_array(B, (uint32_t)sb, 0), *__restrict__ isa1 = rank_array(B, (uint32_t)sb, 1);
+        const uint32_t jj = (b - B.blk_first) / B.blk_step, cap8 = B.bk_cap >> 3, lx = B.bk_affine ? (jj & 7u) : (gi & 7u);
+        // ranges waiting to be dealt: {first rank relative to the group, members, 0: by the rank h0 ahead / 1: 2 h0 ahead}
+        if (tid == 0) {
+            b_big[0][0] = 0;
+            b_big[0][1] = d.cnt;
+            b_big[0][2] = 0;
+            b_bcast[3] = 1;
+            b_bcast[11] = 0;                                                   // a part of the group stays coarse
+        }
+        __syncthreads();
+        for (;;) {
+            const uint32_t depth_ = b_bcast[3];
+            __syncthreads();
+            if (depth_ == 0) break;
+            const uint32_t r0 = b_big[depth_ - 1][0], G = b_big[depth_ - 1][1], sel = b_big[depth_ - 1][2];
+            __syncthreads();
+            uint64_t *__restrict__ sax = B.rec_a + sb * BZX_MAX_N + base + r0;
+            uint64_t *__restrict__ tmp = B.rec_b + sb * BZX_MAX_N + base + r0;      // (dead: the range held the parent bin's records)
+            // ---- the rank ahead of every member; the span of these ranks
+            for (uint32_t i = tid; i < NB + (NB >> 5); i += BS_NT) b_tab[i] = 0;
+            if (tid == 0) {
+                b_bcast[3] = depth_ - 1;                                       // popped
+                b_bcast[1] = 0xFFFFFFFFu;
+                b_bcast[2] = 0;
+                b_bcast[4] = 0;
+            }
+            if (tid < 3) b_bcast[8 + tid] = 0;
+            __syncthreads();
+            {
+                uint32_t mn = 0xFFFFFFFFu, mx = 0;
+                for (uint32_t i = tid; i < G; i += BS_NT) {
+                    const uint32_t rot = (uint32_t)sax[i] & 0xFFFFFu;
+                    uint32_t x = rot + h0;
+                    if (x >= n) x -= n;
+                    if (sel) {
+                        x += h0;
+                        if (x >= n) x -= n;
+                    }
+                    const uint32_t k1 = isa0[x] & ~RK_COARSE;
+                    tmp[i] = ((uint64_t)k1 << 32) | rot;
+                    mn = k1 < mn ? k1 : mn;
+                    mx = k1 > mx ? k1 : mx;
+                }
+                atomicMin(&b_bcast[1], mn);
+                atomicMax(&b_bcast[2], mx);
+            }
+            __syncthreads();
+            const uint32_t lo = b_bcast[1], span = b_bcast[2] - lo;
+            uint32_t nbk = 0;
+            if (span) {
+                const uint32_t sh = span < NB ? 0u : 32u - (uint32_t)__builtin_clz(span) - BS_BIN2;      // (span >> sh) < NB
+                for (uint32_t i = tid; i < G; i += BS_NT) atomicAdd(&TAB(((uint32_t)(tmp[i] >> 32) - lo) >> sh), 1u);
+                __syncthreads();
+                nbk = form_buckets<(int)NB>(G);
+                if (nbk) {
+                    // sub-buckets of one member join a neighbour; b_first[k] becomes the sub-bucket of bucket k, b_start is
+                    // compacted in place; b_cur[k']: members dealt so far, later the item's place, ~0 (coarse) or ~1 (dealt again)
+                    if (tid == 0) {
+                        uint32_t cur = 0, cur_cnt = 0, join_next = 0;
+                        for (uint32_t k = 0; k < nbk; k++) {
+                            const uint32_t st_k = b_start[k], c = b_start[k + 1] - st_k;
+                            const bool fresh = k == 0 || !(join_next || (c == 1 && cur_cnt + 1 <= BS_C));
+                            join_next = 0;
+                            if (fresh) {
+                                if (k) cur++;
+                                b_start[cur] = st_k;
+                                cur_cnt = 0;
+                                if (c == 1 && k + 1 < nbk && 1 + (b_start[k + 2] - b_start[k + 1]) <= BS_C) join_next = 1;
+                            }
+                            cur_cnt += c;
+                            b_first[k] = cur;
+                        }
+                        b_start[cur + 1] = G;
+                        b_bcast[5] = cur + 1;
+                    }
+                    __syncthreads();
+                    const uint32_t nsub_ = b_bcast[5];
+                    for (uint32_t k = tid; k < nsub_; k += BS_NT) b_cur[k] = 0;
+                    __syncthreads();
+                    for (uint32_t i = tid; i < G; i += BS_NT) {
+                        const uint64_t v = tmp[i];
+                        const uint32_t k = b_first[TAB(((uint32_t)(v >> 32) - lo) >> sh)];
+                        const uint32_t slot = atomicAdd(&b_cur[k], 1u);
+                        sax[b_start[k] + slot] = (v & 0xFFFFFull) | (slot == 0 ? 1ull << 32 : 0ull);
+                    }
+                    __syncthreads();
+                }
+            }
+            if (nbk == 0) {
+                // all members share this rank: dealt by the next one, or -- that one shared too, or more than BS_MAX_BK
+                // buckets -- the range stays one group, coarse
+                if (tid == 0) {
+                    if (span == 0 && sel == 0) {
+                        const uint32_t q = b_bcast[3];
+                        b_big[q][0] = r0;
+                        b_big[q][1] = G;
+                        b_big[q][2] = 1;
+                        b_bcast[3] = q + 1;
+                    } else {
+                        b_bcast[4] = 1;
+                        b_bcast[11] = 1;
+                    }
+                }
+                __syncthreads();
+                if (b_bcast[4]) {
+                    for (uint32_t i = tid; i < G; i += BS_NT) {
+                        const uint32_t rot = (uint32_t)sax[i] & 0xFFFFFu;
+                        isa0[rot] = isa1[rot] = base | RK_COARSE;
+                        sax[i] = (uint64_t)rot | (i == 0 ? 1ull << 32 : 0ull);
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
+            const uint32_t nsub = b_bcast[5];
+            // ---- items for the sub-buckets of 2 .. BS_C members, in the block's work list; larger ones are dealt again
+            if (tid == 0) {
+                uint32_t nit = 0, lone = 0, nbig = 0;
+                for (uint32_t k = 0; k < nsub; k++) {
+                    const uint32_t c = b_start[k + 1] - b_start[k];
+                    if (c >= 2 && c <= BS_C) b_cur[k] = nit++;
+                    else if (c > BS_C) {
+                        b_cur[k] = 0xFFFFFFFEu;
+                        nbig++;
+                    } else {
+                        b_cur[k] = 0xFFFFFFFFu;
+                        lone = 1;
+                    }
+                }
+                uint32_t at = nit && !lone ? atomicAdd(&B.counters[BZX_CTR_BK_LIST0 + lx], nit) : 0u;
+                if (lone || at + nit > cap8 || b_bcast[3] + nbig > BS_MAX_BIG) {
+                    // a member alone between two full sub-buckets, or no room in a list: the range stays one group, coarse
+                    for (uint32_t k = 0; k < nsub; k++) b_cur[k] = 0xFFFFFFFFu;
+                    nit = 0;
+                    b_bcast[4] = 1;
+                    b_bcast[11] = 1;
+                } else {
+                    for (uint32_t k = 0; k < nsub; k++) {
+                        if (b_cur[k] == 0xFFFFFFFEu) {
+                            const uint32_t q = b_bcast[3];
+                            b_big[q][0] = r0 + b_start[k];
+                            b_big[q][1] = b_start[k + 1] - b_start[k];
+                            b_big[q][2] = sel;
+                            b_bcast[3] = q + 1;
+                        }
+                    }
+                }
+                b_bcast[6] = lx * cap8 + at;
+                b_bcast[7] = nit ? atomicAdd(&B.counters[BZX_CTR_RK_ITEMS], nit) : 0u;
+                if (nit) {
+                    atomicAdd(&B.counters[BZX_CTR_RK_OPEN], nit);
+                    atomicAdd(&B.blk[b].n_groups, nit);
+                }
+            }
+            __syncthreads();
+            const uint32_t item0 = b_bcast[6], ri0 = b_bcast[7], all_coarse = b_bcast[4];
+            for (uint32_t k = tid; k < nsub; k += BS_NT) {
+                const uint32_t ord = b_cur[k];
+                if (ord < 0xFFFFFFFEu) {
+                    BzxBucket it;
+                    it.blk = b;
+                    it.start = base + r0 + b_start[k];
+                    it.cnt = (b_start[k + 1] - b_start[k]) | 0x80000000u;      // (a bucket that "gave up": the sort kernels leave it alone)
+                    it.dbits = 0;
+                    B.bk_list[item0 + ord] = it;
+                    B.rk_list[ri0 + ord] = item0 + ord;
+                    B.rk_list[B.bk_cap + ri0 + ord] = b_start[k + 1] - b_start[k];
+                }
+            }
+            // ---- the lists of the new items: every member tied, one group
+            for (uint32_t p = tid; p < G; p += BS_NT) {
+                const uint32_t rot = (uint32_t)sax[p] & 0xFFFFFu;
+                if (all_coarse) {
+                    isa0[rot] = isa1[rot] = base | RK_COARSE;
+                    sax[p] = (uint64_t)rot | (p == 0 ? 1ull << 32 : 0ull);
+                    continue;
+                }
+                uint32_t lo_k = 0, hi_k = nsub;                                // sub-bucket of rank p: last k with b_start[k] <= p
+                while (hi_k - lo_k > 1) {
+                    const uint32_t mid = (lo_k + hi_k) >> 1;
+                    if (b_start[mid] <= p) lo_k = mid;
+                    else hi_k = mid;
+                }
+                const uint32_t k = lo_k, j = p - b_start[k];
+                if (b_cur[k] < 0xFFFFFFFEu) {
+                    uint32_t *cl = reinterpret_cast<uint32_t *>(tmp + b_start[k]);
+                    cl[j] = (rot << 12) | ((j == 0 ? 1u : 0u) << 11) | j;
+                }
+            }
+            __syncthreads();
+        }
+        // the open "bucket" emit_giant counted for the group: closed unless a part of it stays coarse
+        if (tid == 0 && b_bcast[11] == 0 && atomicSub(&B.blk[b].n_groups, 1u) == 1u) atomicAnd(&B.blk[b].status, ~BZX_ST_RESUME);
+        __syncthreads();
+    }
+}
+
+void bzx_launch_bgiant(const BzxBatch &B, uint32_t grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bzx_brank_giant_kernel, dim3(grid), dim3(BS_NT), 0, stream, B);
 }
 
 void bzx_launch_brank(const BzxBatch &B, uint32_t grid, hipStream_t stream)

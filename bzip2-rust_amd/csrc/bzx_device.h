@@ -44,6 +44,8 @@
 #define BZX_DEEP_PER_BLOCK 128u    // items of a level's list per block of the batch (a full list: the workgroup splits on by itself)
 #define BZX_CTR_DEEP_CNT 48        // [48..55] oversized bins listed for each level
 #define BZX_CTR_DEEP_FETCH 56      // [56..63] ... fetched
+#define BZX_CTR_GIANT_CNT (BZX_CTR_DEEP_CNT + BZX_DEEP_LEVELS)       // oversized groups listed for the regrouping pass
+#define BZX_CTR_GIANT_FETCH (BZX_CTR_DEEP_FETCH + BZX_DEEP_LEVELS)   // ... fetched
 #define BZX_CTR_BK_FETCH 9         // ... fetched by the bucket sort kernel
 #define BZX_CTR_REDO 10            // blocks handed to the general sorter
 #define BZX_CTR_SPLIT_FETCH 11     // blocks fetched by the split kernel
@@ -137,7 +139,8 @@ struct BzxBatch {
     uint32_t *resume_list;  // [nblk] blocks the general sorter finishes (BZX_ST_RESUME)
     uint32_t *rk_list;      // [2 * allocated items] indices into bk_list of the buckets that gave up; [bk_cap + i]: tied ranks of
                             // bucket rk_list[i] (entries of its compact list, see the rank rounds)
-    uint32_t *deep_list;    // [2][deep_cap] items of 16 B: oversized bins of the level being split / of the next one (zeroed per batch)
+    uint32_t *deep_list;    // [3][deep_cap] items of 16 B: oversized bins of the level being split / of the next one (zeroed per
+                            // batch); [2]: the oversized groups the split gave up on (regrouping pass before the rank rounds)
     uint32_t deep_cap;
     uint32_t deep_lvl;      // level of this launch of the deep-split kernel
     uint32_t *isa2;         // [blocks][2][BZX_MAX_N] two rank arrays per block in resume state (index: its place in resume_list)
