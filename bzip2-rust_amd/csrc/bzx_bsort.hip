@@ -2036,14 +2036,19 @@ __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_brank_round_kern
 // partition: the members are dealt into sub-buckets by the rank h0 ahead (4,096 bins over the range the ranks of the
 // members span, adjacent bins merged into buckets of at most BS_C as in the split) -- sub-bucket k holds smaller ranks
 // than sub-bucket k + 1, inside a sub-bucket the order is open.  A sub-bucket that is still too big is dealt again: by
-// the same rank over its narrower span, and once all its members share that rank, by the rank 2 h0 ahead.  Every
+// the same rank over its narrower span, and once all its members share that rank, by the rank 2 h0 ahead, then 3 h0,
+// .. (every rank in the array is at least h0 deep wherever it is read, so the sequence of ranks h0, 2 h0, 3 h0, ..
+// ahead orders the members like their text; round 0 looks at the first two and finds them equal, which is right).  Every
 // sub-bucket of 2 .. BS_C members becomes an ordinary item of the rank rounds whose ranks are all tied in ONE group,
 // and round 0 does the rest.  The rank arrays are not touched (round 0 readers still see the old group-head rank of
 // the members, which is as deep as round 0 assumes -- and other workgroups of this launch may be reading it: a reader
 // must not see some members of a group refined and others not; round 0 itself enters the new ranks into the other
-// array).  What cannot be dealt -- more than BS_C members with the same two ranks ahead: padding patterns -- stays one
+// array).  What cannot be dealt -- more than BS_C members with the same BS_GIANT_KEYS ranks ahead: padding patterns -- stays one
 // group with coarse ranks as before, and so does a range in which a member would end up alone between two full
 // sub-buckets (its rank would be final, and a final rank has to enter both rank arrays, which only a round can do).
+#ifndef BS_GIANT_KEYS
+#define BS_GIANT_KEYS 16
+#endif
 __global__ __launch_bounds__(BS_NT) void bzx_brank_giant_kernel(BzxBatch B)
 {
     const uint32_t tid = threadIdx.x;
@@ -2065,7 +2070,7 @@ __global__ __launch_bounds__(BS_NT) void bzx_brank_giant_kernel(BzxBatch B)
         const size_t sb = BZX_SLAB(B, b);
         uint32_t *__restrict__ isa0 = rank_array(B, (uint32_t)sb, 0), *__restrict__ isa1 = rank_array(B, (uint32_t)sb, 1);
         const uint32_t jj = (b - B.blk_first) / B.blk_step, cap8 = B.bk_cap >> 3, lx = B.bk_affine ? (jj & 7u) : (gi & 7u);
-        // ranges waiting to be dealt: {first rank relative to the group, members, 0: by the rank h0 ahead / 1: 2 h0 ahead}
+        // ranges waiting to be dealt: {first rank relative to the group, members, s: by the rank (s + 1) h0 ahead}
         if (tid == 0) {
             b_big[0][0] = 0;
             b_big[0][1] = d.cnt;
@@ -2096,12 +2101,7 @@ __global__ __launch_bounds__(BS_NT) void bzx_brank_giant_kernel(BzxBatch B)
                 uint32_t mn = 0xFFFFFFFFu, mx = 0;
                 for (uint32_t i = tid; i < G; i += BS_NT) {
                     const uint32_t rot = (uint32_t)sax[i] & 0xFFFFFu;
-                    uint32_t x = rot + h0;
-                    if (x >= n) x -= n;
-                    if (sel) {
-                        x += h0;
-                        if (x >= n) x -= n;
-                    }
+                    const uint32_t x = (uint32_t)((rot + (uint64_t)(sel + 1u) * h0) % n);
                     const uint32_t k1 = isa0[x] & ~RK_COARSE;
                     tmp[i] = ((uint64_t)k1 << 32) | rot;
                     mn = k1 < mn ? k1 : mn;
@@ -2156,11 +2156,11 @@ __global__ __launch_bounds__(BS_NT) void bzx_brank_giant_kernel(BzxBatch B)
                 // all members share this rank: dealt by the next one, or -- that one shared too, or more than BS_MAX_BK
                 // buckets -- the range stays one group, coarse
                 if (tid == 0) {
-                    if (span == 0 && sel == 0) {
+                    if (span == 0 && sel + 1u < BS_GIANT_KEYS) {
                         const uint32_t q = b_bcast[3];
                         b_big[q][0] = r0;
                         b_big[q][1] = G;
-                        b_big[q][2] = 1;
+                        b_big[q][2] = sel + 1u;
                         b_bcast[3] = q + 1;
                     } else {
                         b_bcast[4] = 1;
