@@ -432,7 +432,8 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         // this launch's share of the bucket work lists: eight lists of items / 8 (cap_slabs >= 16, so at least 4096 each);
         // ALL of it is zeroed, so an item the split kernel reserved but did not write is an empty one
         const size_t cap_all = (size_t)ctx->cap_slabs * BZX_BK_PER_BLOCK;
-        const size_t items = ((size_t)nblk * BZX_BK_PER_BLOCK < cap_all ? (size_t)nblk * BZX_BK_PER_BLOCK : cap_all) & ~(size_t)7;
+        const size_t want = (size_t)(nblk < 16 ? 16 : nblk) * BZX_BK_PER_BLOCK;       // (a lone repetitive block emits thousands of one-bucket splits)
+        const size_t items = (want < cap_all ? want : cap_all) & ~(size_t)7;
         B.bk_cap = (uint32_t)items;
         // few blocks: their buckets are dealt over all eight lists, so that every compute unit gets work; many: a list
         // holds whole blocks (one L2 per block)

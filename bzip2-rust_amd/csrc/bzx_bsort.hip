@@ -222,10 +222,13 @@ __device__ __forceinline__ void bucket_setup(uint32_t nbk)
 // Returns false when the big list is full.
 template <int BINW>
 __device__ __forceinline__ bool bucket_emit(const BzxBatch &B, uint32_t blk, uint32_t jj, uint32_t nbk, uint32_t base, uint32_t buf,
-                                            uint32_t depth, uint32_t bits, uint32_t done)
+                                            uint32_t depth, uint32_t bits, uint32_t done, uint32_t salt)
 {
-    // jj: index of the block in the launch.  The nbk items go to list jj % 8 (bk_affine), or item k to list (jj + k) % 8.
+    // jj: index of the block in the launch.  The nbk items go to list jj % 8 (bk_affine), or item k to list (jj + salt + k) % 8
+    // (salt: the number of the split within the block -- a small batch of repetitive blocks emits hundreds of one-bucket
+    // splits, and they must not all land in the same eighth of the work list).
     const uint32_t tid = threadIdx.x, cap8 = B.bk_cap >> 3;
+    if (!B.bk_affine) jj += salt;
     if (tid < 8) {
         const uint32_t mine = B.bk_affine ? (tid == (jj & 7u) ? nbk : 0u) : (nbk + 7u - ((tid - jj) & 7u)) >> 3;
         uint32_t at = mine ? atomicAdd(&B.counters[BZX_CTR_BK_LIST0 + tid], mine) : 0u;
@@ -406,7 +409,7 @@ __device__ bool deep_process(const BzxBatch &B, uint32_t b, uint32_t j_, uint32_
             dst[b_start[k] + slot] = ((uint64_t)key << 32) | (r & 0xFFFFFFFFull);
         }
         __syncthreads();
-        ok = bucket_emit<BS_BIN2>(B, b, j_, nbk, base, buf ^ 1u, depth, bits, done);
+        ok = bucket_emit<BS_BIN2>(B, b, j_, nbk, base, buf ^ 1u, depth, bits, done, spent + 1u);
         DIAG_COUNT(104, 1);
         DIAG_COUNT(105, cnt);
     }
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(BS_NT) void bzx_bsplit_kernel(BzxBatch B)
         }
         __syncthreads();
         DIAG_STAMP(101);
-        bool ok = bucket_emit<BS_BIN1>(B, b, j_, nbk, 0, 0, 0, bits, 0);
+        bool ok = bucket_emit<BS_BIN1>(B, b, j_, nbk, 0, 0, 0, bits, 0, 0);
         DIAG_STAMP(102);
 
         // ---- deeper levels: every oversized bin is split again by its next BS_BIN2 bits (deep_process): by the launches

@@ -128,6 +128,20 @@ def test_emu_leftover_groups_paths(emu, oracle):
     assert st.n_periodic == 1
 
 
+def test_emu_oversized_group_regrouped(emu):
+    """2,100 copies of one 65-byte string, each followed by four random bytes: the rotations at the start of a copy
+    agree on more than the split's whole depth with 2,099 others -- a group too big for a workgroup's rank round.  The
+    regrouping pass (bzx_brank_giant_kernel) deals it into ordinary rank-round items by the ranks ahead, and the rounds
+    finish the block: nothing is left to the general sorter, and the block is not refused although the split emits
+    thousands of one-bucket splits for it (a lone block's share of the work lists)."""
+    rnd = random.Random(5)
+    unit = rnd.randbytes(65)
+    data = b"".join(unit + rnd.randbytes(4) for _ in range(2100))
+    assert emu.compress_buffer(data, 9) == bz2.compress(data, 9)
+    st = emu.stats()
+    assert st.n_open_buckets > 0 and st.n_open_left == 0 and st.n_resume_left == 0 and st.n_from_scratch == 0
+
+
 def test_emu_concurrent_compress_block(emu, oracle):
     """bzx_compress_block from several host threads on one context (the reference calls compress_block from every
     rayon worker, compress.rs:125-132): calls are collected into device batches, every caller gets its own result."""

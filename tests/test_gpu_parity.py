@@ -400,6 +400,16 @@ def test_leftover_groups_paths(bzx, oracle):
     st = bzx.stats()
     assert out == bz2.compress(tiny, 9)
     assert st.n_periodic == 1 and st.n_resume_left == 1
+    # (d) thousands of copies of one string with different continuations: oversized groups that the regrouping pass
+    # deals into rank-round items -- nothing left to the general sorter, nothing refused (alone and inside text)
+    rnd = random.Random(5)
+    unit = rnd.randbytes(65)
+    copies = b"".join(unit + rnd.randbytes(4) for _ in range(2100))
+    for data in (copies, big[:300_000] + copies + big[300_000:600_000]):
+        out = bzx.compress_buffer(data, 9)
+        st = bzx.stats()
+        assert out == bz2.compress(data, 9)
+        assert st.n_open_buckets > 0 and st.n_resume_left == 0 and st.n_from_scratch == 0
 
 
 def test_deep_repeats(bzx, oracle):
