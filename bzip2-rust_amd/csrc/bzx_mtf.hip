@@ -362,13 +362,24 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
             uint32_t *stp = reinterpret_cast<uint32_t *>(m_list);       // [MTF_NT * 16] their positions
             static_assert(MTF_LIST_BYTES >= MTF_NT * MTF_E * 4, "tile staging");
             uint32_t done = 0;                                          // heads of the earlier tiles
+            // (the next tile's bytes are loaded while this one is compacted: a tile is four barriers and little else, and
+            // the load at its top was a quarter of the pass)
+            uint4 vn = make_uint4(0, 0, 0, 0);
+            uint32_t pn = 0x100;                                        // (no byte: position 0 is a head)
+            if (tid * MTF_E < n) {
+                vn = *reinterpret_cast<const uint4 *>(L + tid * MTF_E); // bytes past n are ignored below
+                if (tid) pn = L[tid * MTF_E - 1];
+            }
             for (uint32_t t0 = 0; t0 < n; t0 += MTF_NT * MTF_E) {
                 const uint32_t i0 = t0 + tid * MTF_E;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                uint32_t prev = 0x100;                                  // (no byte: position 0 is a head)
-                if (i0 < n) {
-                    v = *reinterpret_cast<const uint4 *>(L + i0);       // bytes past n are ignored below
-                    if (i0) prev = L[i0 - 1];
+                const uint4 v = vn;
+                uint32_t prev = pn;
+                {
+                    const uint32_t i1 = i0 + MTF_NT * MTF_E;
+                    if (i1 < n) {
+                        vn = *reinterpret_cast<const uint4 *>(L + i1);
+                        pn = L[i1 - 1];
+                    }
                 }
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
                 uint32_t hm = 0;
@@ -550,17 +561,34 @@ __global__ __launch_bounds__(MTF_NT) void bzx_mtf_kernel(BzxBatch B)
         // (a tile's symbols fit: H heads of runs l_i emit H + sum floor(log2 l_i) symbols, sum l_i <= 900,000; for H = 8,192
         // that is at most 8,192 * 7 + 5,875 = 63,219 symbols of 2 bytes)
         static_assert(2 * MTF_LIST_BYTES >= 2 * 64000, "symbol staging of a tile");
+        // (the next tile's ranks and positions are loaded while this one is coded, as in pass 1)
+        uint2 rvn = make_uint2(0, 0);
+        uint32_t ppn[HE + 1];
+#pragma unroll
+        for (uint32_t k = 0; k <= HE; k++) ppn[k] = n;
+        if (tid * HE < nh) {
+            __builtin_memcpy(&rvn, H + tid * HE, 8);                    // (8-byte aligned: a multiple of 8)
+#pragma unroll
+            for (uint32_t k = 0; k <= HE; k++) ppn[k] = tid * HE + k <= nh ? P[tid * HE + k] : n;
+        }
         for (uint32_t t0 = 0; t0 < nh; t0 += MTF_NT * HE) {
             const uint32_t k0 = t0 + tid * HE;
             const uint32_t carry_out = m_bcast[2];
             uint32_t rk[HE], zr[HE];
             uint32_t my_cnt = 0;
-            if (k0 < nh) {
-                uint2 rv;
-                __builtin_memcpy(&rv, H + k0, 8);                       // (8-byte aligned: k0 is a multiple of 8)
-                uint32_t pp[HE + 1];
+            const uint2 rv = rvn;
+            uint32_t pp[HE + 1];
 #pragma unroll
-                for (uint32_t k = 0; k <= HE; k++) pp[k] = k0 + k <= nh ? P[k0 + k] : n;
+            for (uint32_t k = 0; k <= HE; k++) pp[k] = ppn[k];
+            {
+                const uint32_t k1 = k0 + MTF_NT * HE;
+                if (k1 < nh) {
+                    __builtin_memcpy(&rvn, H + k1, 8);
+#pragma unroll
+                    for (uint32_t k = 0; k <= HE; k++) ppn[k] = k1 + k <= nh ? P[k1 + k] : n;
+                }
+            }
+            if (k0 < nh) {
 #pragma unroll
                 for (uint32_t k = 0; k < HE; k++) {
                     rk[k] = ((k < 4 ? rv.x : rv.y) >> (8 * (k & 3))) & 255u;
