@@ -135,7 +135,10 @@ __device__ void make_code_lengths(int t, int32_t alpha, int32_t max_len)
         }                                                                     \
     } while (0)
 
-__global__ __launch_bounds__(HUF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void bzx_huff_kernel(BzxBatch B)
+#ifndef HUF_WAVES_PER_SIMD
+#define HUF_WAVES_PER_SIMD 6            // three workgroups per compute unit (48 KB of LDS each)
+#endif
+__global__ __launch_bounds__(HUF_NT) __attribute__((amdgpu_waves_per_eu(HUF_WAVES_PER_SIMD, HUF_WAVES_PER_SIMD))) void bzx_huff_kernel(BzxBatch B)
 {
     const uint32_t tid = threadIdx.x, lane = bzx_lane(), wave = bzx_wave();
     unsigned long long t_last = 0;

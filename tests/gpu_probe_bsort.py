@@ -48,6 +48,7 @@ def run(name, data, ref="oracle"):
         print("   huffman (us per block): " + "  ".join(f"{v} {t[k]/100.0/nb:.0f}" for k, v in
               {40: "setup", 41: "costs+freq x4", 42: "code-lengths x4", 43: "codes", 44: "payload-bits", 45: "selector-mtf"}.items()))
         print("   mtf (us per block): " + "  ".join(f"s{k} {t[k]/100.0/nb:.0f}" for k in range(32, 40)))
+        print("   emit (us per block): " + "  ".join(f"s{k} {t[k]/100.0/nb:.0f}" for k in range(48, 52)))
         gen = {0: "A+hist", 1: "lsd4", 2: "rerank0", 3: "tail", 4: "rank-rerank", 5: "isa-build", 6: "rank-segsort", 7: "rank-bigsplit"}
         tg = sum(t[i] for i in range(32)) or 1
         print("   general sorter: " + "  ".join(f"{v} {t[k]/100.0/max(1,st.n_redo):.0f}us" for k, v in gen.items()),
