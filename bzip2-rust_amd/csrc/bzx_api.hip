@@ -471,11 +471,12 @@ static int run_stages(bzx_ctx *ctx, uint32_t nblk, int stages, int out_level = 0
         HIP_TRY(ctx, hipEventRecord(ctx->ev_b2, ctx->stream));
         ctx->bsort_used = true;
         // the blocks in which a bucket gave up (deep repeats): the fill pass writes the order of their finished
-        // buckets and enters their ranks into the block's rank array (inside the general sorter's slots from rk_slot0
-        // on), prefix-doubling rounds over the open buckets finish the leftover groups -- any workgroup on any bucket,
-        // each launch exits at once when nothing is open.  Then the general sorter takes what is left: refused blocks
-        // beyond the early launch's 32, and resume blocks still open after the rank rounds (periodic blocks, blocks
-        // with an oversized group and the buckets that read its coarse ranks, stress builds: blocks without rank arrays).
+        // buckets and enters their ranks into the block's two rank arrays, the regrouping pass turns oversized groups
+        // into ordinary items, prefix-tripling rank rounds over the open buckets finish the leftover groups -- any
+        // workgroup on any bucket, each launch exits at once when nothing is open.  Then the general sorter takes what is
+        // left: refused blocks beyond the early launch's 32, and resume blocks still open after the rank rounds (periodic
+        // blocks, oversized groups the regrouping pass could not dissolve and the groups that read their coarse ranks,
+        // stress builds: blocks without rank arrays).
         BzxBatch Bf = B;
         Bf.bsort_mode = 1;
         bzx_launch_bsort(Bf, bzx_bsort_blocks_per_cu() * ncu, ctx->stream);

@@ -20,8 +20,8 @@
 // A bucket that is still tied after BS_ROUNDS rounds (repeats of hundreds of symbols; identical rotations of a
 // periodic block) keeps what it has: it writes its order so far and its group starts, and the block goes on
 // B.resume_list; a second, short launch of the sort kernel (the fill pass) writes the order of that block's finished
-// buckets, and the general sorter (bzx_bwt.hip) runs its prefix-doubling rounds on the leftover groups only -- it also
-// detects periodic blocks.  Blocks the split kernel cannot handle (more split levels than BS_MAX_BIG
+// buckets, the rank rounds (below) finish the leftover groups bucket by bucket, and the general sorter (bzx_bwt.hip)
+// runs its prefix-doubling rounds on whatever they leave -- it also detects periodic blocks.  Blocks the split kernel cannot handle (more split levels than BS_MAX_BIG
 // tracks) are sorted from scratch by the general sorter (B.redo_list).
 #include <hip/hip_runtime.h>
 #include "bzx_device.h"
@@ -279,7 +279,7 @@ __device__ __forceinline__ uint32_t *rank_array(const BzxBatch &B, uint32_t k, u
 // An oversized bin the split gives up on (depth or split limit: thousands of rotations sharing a long prefix -- table
 // borders, padding patterns) is left as ONE group of tied ranks in the resume format ([group start:1 @32 | rotation:20],
 // see the sort kernel) and the block joins the resume blocks.  The rank rounds cannot refine such a group (it does not
-// fit a workgroup), and doubling the depth is only valid where every rank read is as deep as the round assumes: so the
+// fit a workgroup), and multiplying the depth is only valid where every rank read is as deep as the round assumes: so the
 // members' entries in both rank arrays carry RK_COARSE, a bucket that reads a coarse rank leaves the rounds with its own
 // tied ranks marked coarse too (see the rank rounds), and the general sorter finishes whatever is left of the block --
 // this group, those buckets -- afterwards.  (Until round 3 such a block went to the general sorter with ALL its tied
@@ -1541,7 +1541,7 @@ __device__ __forceinline__ void bsort_body(const BzxBatch &B)
 __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bsort_kernel(BzxBatch B) { bsort_body(B); }
 __global__ __launch_bounds__(SK_NT, SK_WAVES_PER_SIMD) void bzx_bfill_kernel(BzxBatch B) { bsort_body(B); }
 
-// ---- rank rounds: the buckets that gave up, finished by prefix doubling ---------------------------------------
+// ---- rank rounds: the buckets that gave up, finished by prefix tripling ---------------------------------------
 // A bucket gives up when some of its rotations still agree after BS_ROUNDS refinement rounds (deep repeats: duplicated
 // files, licence headers, tables in binaries).  Its order and group starts were written back for ALL its ranks (the
 // general sorter's fall-back) and once more, for the TIED ranks only, as a compact list of 4-byte entries; the fill
